@@ -1,0 +1,213 @@
+/* rt.h -- C ABI of the MI355X render hot path (libraytracer_amd.so).
+ *
+ * The reference (rfsmi/raytracer) is a single Rust binary with no FFI seam;
+ * this header is the seam a maintainer would bind.  Each entry point names
+ * the reference item it stands in for (paths relative to the reference
+ * checkout).  Plain pointers and sizes only; all host buffers are owned by
+ * the caller; the library copies what it keeps.
+ *
+ * Conventions
+ *  - Every function returns 0 on success or an rt_status code; the message of
+ *    the last failure on the calling thread is rt_last_error().  Nothing
+ *    throws or aborts across this boundary (the reference panics instead:
+ *    src/camera.rs:160, src/bvh.rs:191).
+ *  - A scene lives on the HIP device that was current when it was created.
+ *    It is immutable afterwards, so calls on one scene may come from several
+ *    host threads.
+ *  - Results depend only on (scene, config, seed, sample range, tile), never
+ *    on scheduling.
+ *  - There is no CPU fallback: without a usable HIP device every compute
+ *    entry point fails with RT_ERR_HIP.
+ */
+#ifndef RAYTRACER_AMD_RT_H
+#define RAYTRACER_AMD_RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID = 1, /* bad argument (null pointer, non-finite input, empty range ...) */
+  RT_ERR_HIP = 2,     /* a HIP runtime call failed; rt_last_error() has the call and HIP's text */
+  RT_ERR_IO = 3,      /* file output failed */
+  RT_ERR_LIMIT = 4    /* input exceeds a documented limit */
+} rt_status;
+
+/* Material kinds: src/material.rs:10-19 (Lambertian, Metal, Dielectric). */
+enum { RT_LAMBERTIAN = 0, RT_METAL = 1, RT_DIELECTRIC = 2 };
+
+/* One `Arc<dyn Material>` flattened.  param is Metal::fuzz or Dielectric::ir. */
+typedef struct rt_material {
+  uint32_t type;
+  uint32_t reserved;
+  double albedo[3];
+  double param;
+} rt_material;
+
+/* One `Sphere` (src/sphere.rs:12-16); material indexes the rt_material array. */
+typedef struct rt_sphere {
+  double center[3];
+  double radius;
+  uint32_t material;
+  uint32_t reserved;
+} rt_sphere;
+
+/* `Config` (src/camera.rs:15-26): same ten fields, same meaning. */
+typedef struct rt_config {
+  double aspect_ratio;
+  uint32_t image_width;
+  uint32_t reserved;
+  uint64_t samples_per_pixel;
+  uint64_t max_depth;
+  double vfov;
+  double lookfrom[3];
+  double lookat[3];
+  double vup[3];
+  double defocus_angle;
+  double focus_dist;
+} rt_config;
+
+/* Derived `Camera` fields (src/camera.rs:28-37). */
+typedef struct rt_camera {
+  uint32_t image_height;
+  uint32_t reserved;
+  double center[3];
+  double pixel00_loc[3];
+  double pixel_delta_u[3];
+  double pixel_delta_v[3];
+  double defocus_disk_u[3];
+  double defocus_disk_v[3];
+} rt_camera;
+
+/* Half-open pixel rectangle [x0,x1) x [y0,y1). */
+typedef struct rt_rect {
+  uint32_t x0, y0, x1, y1;
+} rt_rect;
+
+/* What one render call did.  kernel_ms is measured with HIP events on the
+ * stream the kernels ran on. */
+typedef struct rt_render_stats {
+  uint64_t rays;        /* closest-hit queries (primary + secondary), one per BVH::hit call of the reference */
+  uint64_t samples;     /* camera paths started */
+  float kernel_ms;      /* device time of the launch(es) of this call */
+  uint32_t launches;    /* kernels launched by this call */
+} rt_render_stats;
+
+typedef struct rt_scene_info {
+  uint64_t n_spheres;
+  uint64_t n_nodes;
+  uint32_t depth;           /* levels in the BVH (a single leaf has depth 1) */
+  uint32_t n_nodes_in_lds;  /* nodes of the top of the tree staged in LDS by the kernels */
+  uint32_t spheres_in_lds;  /* 1 when the sphere records are staged in LDS too */
+  uint32_t device;          /* HIP device ordinal the scene lives on */
+  uint64_t device_bytes;    /* HBM held by the scene */
+  double build_ms;          /* host BVH build + flatten */
+} rt_scene_info;
+
+typedef struct rt_scene rt_scene;
+
+/* Message of the last failure on this thread ("" if none). */
+const char* rt_last_error(void);
+
+/* `Config::new()` defaults (src/camera.rs:15-26). */
+void rt_config_default(rt_config* cfg);
+
+/* `Config::camera()` (src/camera.rs:40-82). Host only. */
+int rt_camera_derive(const rt_config* cfg, rt_camera* out);
+
+/* `BVH::new(objects)` (src/bvh.rs:44-48, builder :92-266 without the unfinished
+ * spatial splits): copies the inputs, builds the binned-SAH tree on the host,
+ * flattens it and uploads it to the current HIP device. */
+int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_material* materials, size_t n_materials, rt_scene** out);
+int rt_scene_destroy(rt_scene* scene);
+int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
+
+/* Host-only: the tree `BVH::new` builds, without a device (src/bvh.rs:44-48).
+ * Used to compare the builder with the reference's algorithm node by node. */
+typedef struct rt_host_bvh rt_host_bvh;
+int rt_bvh_build(const rt_sphere* spheres, size_t n_spheres, rt_host_bvh** out);
+int rt_bvh_destroy(rt_host_bvh* bvh);
+int rt_bvh_counts(const rt_host_bvh* bvh, uint64_t* n_nodes, uint64_t* n_leaf_indices, uint32_t* depth);
+/* Same layout as rt_scene_bvh_dump. */
+int rt_bvh_dump(const rt_host_bvh* bvh, double* boxes, int32_t* kind, uint64_t* skip_or_count, uint64_t* leaf_indices);
+
+/* The host tree in the reference's own order (pre-order; a split's left child
+ * follows it and its right child is `skip` entries later: src/bvh.rs:125-132).
+ * boxes: n_nodes x 6 doubles (min, max); kind: 0..2 split axis, 3 leaf;
+ * skip_or_count: skip (split) or primitive count (leaf); leaf_indices: the
+ * leaves' sphere indices concatenated in node order (n_spheres entries).
+ * Any output pointer may be NULL. */
+int rt_scene_bvh_dump(const rt_scene* scene, double* boxes, int32_t* kind, uint64_t* skip_or_count, uint64_t* leaf_indices);
+
+/* `BVH::hit(&Ray, Interval)` over a batch (src/bvh.rs:50-84 with
+ * src/aabb.rs:69-82, src/sphere.rs:29-48, src/hit.rs:18-27).  Rays are built
+ * as `Ray::new` does (src/ray.rs:16-23): dir need not be normalised.  Host
+ * buffers: org, dir, normal are n x 3 doubles.  prim is the index into the
+ * array given to rt_scene_create, -1 where the reference returns None (then
+ * t is +inf and normal 0). */
+int rt_trace_batch(const rt_scene* scene, const double* org, const double* dir, size_t n, double t_min, double t_max, int32_t* prim,
+                   double* t, double* normal, uint8_t* front_face);
+
+/* `Material::scatter(&Ray, &HitRecord)` over a batch (src/material.rs:21-65)
+ * with the randomness passed in: u is n x 2 uniforms in [0,1).  The unit
+ * vector of `vector::random_unit()` is the direct map z = 1-2u0, phi = 2 pi u1;
+ * the Dielectric's `random::<f64>()` is u0.  in_dir is normalised first, as the
+ * incoming Ray would be.  scattered[i] = 0 where the reference returns None.
+ * out_dir is the direction of the scattered Ray (unit length); its origin is p. */
+int rt_scatter_batch(const rt_scene* scene, const uint32_t* material, const double* in_dir, const double* p, const double* normal,
+                     const uint8_t* front_face, const double* u, size_t n, uint8_t* scattered, double* attenuation, double* out_dir);
+
+/* The device's node test, `AABB::ray_intersection(..).is_some()`
+ * (src/aabb.rs:69-82), over a batch.  The kernels test nodes in f32 against
+ * boxes rounded outwards and padded so that the answer is never "miss" where
+ * the reference's f64 test says "hit"; it may say "hit" for rays that pass
+ * within rounding distance of a box.  boxes: n x 6 doubles; interval: n x 2. */
+int rt_slab_batch(const double* boxes, const double* org, const double* dir, const double* interval, size_t n, uint8_t* hit);
+
+/* Primary rays, `Camera::get_ray(i, j)` (src/camera.rs:114-136), for n
+ * (i, j, sample) triples under the library's counter-based RNG. */
+int rt_primary_rays(const rt_config* cfg, uint64_t seed, const uint32_t* ijs, size_t n, double* org, double* dir);
+
+/* The parallel part of `Camera::render` (src/camera.rs:140-155): for every
+ * pixel of `tile` (NULL = whole image) adds the radiance of samples
+ * [spp_begin, spp_end) into rgb_sum, a row-major image_width x image_height x 3
+ * array of doubles.  cfg->samples_per_pixel is not read here (the sample range
+ * is explicit); cfg->max_depth is.  Sample s of pixel (i,j) is the same path
+ * whatever the tile or range, so tiles and ranges can be split over GPUs.
+ *
+ * rt_render: rgb_sum is host memory; returns when it has been updated.
+ * rt_render_device: rgb_sum is device memory on the scene's device; the
+ * kernels run on `stream` (a hipStream_t, NULL = default stream) and the call
+ * returns when they have finished (it waits for the stream).  stats may be
+ * NULL. */
+int rt_render(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile,
+              double* rgb_sum, rt_render_stats* stats);
+int rt_render_device(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
+                     const rt_rect* tile, double* rgb_sum_dev, void* stream, rt_render_stats* stats);
+
+/* `write_colour` (src/camera.rs:85-95) for n pixels: out is n x 3 bytes. Host only. */
+int rt_quantise(const double* rgb_sum, size_t n_pixels, uint64_t samples_per_pixel, uint8_t* out);
+
+/* The text the reference prints (src/camera.rs:139,157-164): "P3\n{w} {h}\n255\n"
+ * then one "r g b\n" line per pixel.  fd is an open file descriptor (1 = stdout). */
+int rt_write_ppm(int fd, const double* rgb_sum, uint32_t width, uint32_t height, uint64_t samples_per_pixel);
+
+/* Seeded restatement of the scene of src/main.rs:42-82 (4 fixed spheres and a
+ * 22 x 22 grid; 488 spheres, 488 materials).  Both arrays must hold 488 entries. */
+int rt_scene_rtiow(uint64_t seed, rt_sphere* spheres, rt_material* materials);
+
+/* Synthetic fields for stress configurations: ground sphere plus n_small
+ * spheres of radius 0.2 on a jittered square grid, materials drawn with the
+ * given probabilities (lambertian, metal; the rest glass), metal fuzz uniform
+ * in [0, max_fuzz).  Arrays must hold n_small + 1 entries. */
+int rt_scene_field(uint64_t seed, size_t n_small, double p_lambertian, double p_metal, double max_fuzz, rt_sphere* spheres,
+                   rt_material* materials);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

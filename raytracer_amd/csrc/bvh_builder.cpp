@@ -1,0 +1,231 @@
+#include "bvh_builder.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rta {
+namespace {
+
+const double kInf = std::numeric_limits<double>::infinity();
+const double kLeafCost = 1.0;         // src/bvh.rs:87
+const double kSplitCost = 1.0 / 8.0;  // src/bvh.rs:88
+const int kBuckets = 32;              // src/bvh.rs:89
+
+inline Box empty_box() {  // AABB::new, src/aabb.rs:11-16
+  return Box{{kInf, kInf, kInf}, {-kInf, -kInf, -kInf}};
+}
+inline void grow(Box& a, const Box& b) {  // AABB::update / union, src/aabb.rs:36-38,48-53
+  for (int k = 0; k < 3; ++k) {
+    a.min[k] = std::fmin(a.min[k], b.min[k]);
+    a.max[k] = std::fmax(a.max[k], b.max[k]);
+  }
+}
+inline double surface_area(const Box& b) {  // src/aabb.rs:31-34
+  double x = b.max[0] - b.min[0], y = b.max[1] - b.min[1], z = b.max[2] - b.min[2];
+  return 2.0 * (x * y + x * z + z * y);
+}
+// Key that orders doubles as f64::total_cmp does (min_by at src/bvh.rs:227).
+inline int64_t total_order_key(double v) {
+  int64_t b;
+  std::memcpy(&b, &v, 8);
+  b ^= (int64_t)((uint64_t)(b >> 63) >> 1);
+  return b;
+}
+// src/bvh.rs:250-258; the cast saturates and maps NaN to 0 as Rust's `as usize` does.
+inline int choose_bucket(double min_t, double max_t, double t) {
+  double f = (t - min_t) / (max_t - min_t);
+  double scaled = (double)kBuckets * f;
+  if (!(scaled > 0.0)) return 0;
+  if (scaled >= (double)kBuckets) return kBuckets - 1;  // f == 1 for the largest centroid
+  return (int)scaled;
+}
+
+struct Builder {
+  std::vector<Box> prim_box;            // Sphere::aabb, src/sphere.rs:50-52
+  std::vector<double> centroid[3];      // AABB::centroid, src/aabb.rs:23-25
+  std::vector<uint64_t> idx, tmp;
+  HostBvh out;
+
+  void build(size_t lo, size_t hi, uint32_t depth) {
+    const size_t n = hi - lo;
+    out.depth = std::max(out.depth, depth);
+    Box box = empty_box();
+    for (size_t k = lo; k < hi; ++k) grow(box, prim_box[idx[k]]);
+
+    // Bounds of the centroids (AABB::bounding_box, src/aabb.rs:40-46).
+    double cmin[3] = {kInf, kInf, kInf}, cmax[3] = {-kInf, -kInf, -kInf};
+    if (n > 0) {
+      for (int a = 0; a < 3; ++a) cmin[a] = cmax[a] = centroid[a][idx[lo]];
+      for (size_t k = lo + 1; k < hi; ++k)
+        for (int a = 0; a < 3; ++a) {
+          double c = centroid[a][idx[k]];
+          cmin[a] = std::fmin(cmin[a], c);
+          cmax[a] = std::fmax(cmax[a], c);
+        }
+    }
+
+    bool have = false;
+    int best_axis = 0, best_split = 0;
+    double best_cost = 0.0;
+    const double node_area = surface_area(box);
+    for (int axis = 0; axis < 3; ++axis) {  // iter_bounds_axes, src/bvh.rs:196-201
+      if (!((cmax[axis] - cmin[axis]) > 0.0)) continue;
+      Box bbox[kBuckets];
+      uint64_t bcount[kBuckets];
+      for (int b = 0; b < kBuckets; ++b) {
+        bbox[b] = empty_box();
+        bcount[b] = 0;
+      }
+      for (size_t k = lo; k < hi; ++k) {
+        int b = choose_bucket(cmin[axis], cmax[axis], centroid[axis][idx[k]]);
+        bcount[b]++;
+        grow(bbox[b], prim_box[idx[k]]);
+      }
+      // Suffix unions, then one forward sweep: the same boxes and counts that
+      // combine_buckets (src/bvh.rs:260-266) yields for every split point,
+      // because min/max are exact and associative.
+      Box suffix[kBuckets + 1];
+      uint64_t suffix_n[kBuckets + 1];
+      suffix[kBuckets] = empty_box();
+      suffix_n[kBuckets] = 0;
+      for (int b = kBuckets - 1; b >= 0; --b) {
+        suffix[b] = bbox[b];
+        grow(suffix[b], suffix[b + 1]);
+        suffix_n[b] = bcount[b] + suffix_n[b + 1];
+      }
+      Box prefix = empty_box();
+      uint64_t prefix_n = 0;
+      for (int i = 1; i < kBuckets; ++i) {
+        grow(prefix, bbox[i - 1]);
+        prefix_n += bcount[i - 1];
+        double cost = kSplitCost + kLeafCost * ((double)prefix_n * surface_area(prefix) + (double)suffix_n[i] * surface_area(suffix[i])) /
+                                       node_area;  // src/bvh.rs:218-226
+        if (!have || total_order_key(cost) < total_order_key(best_cost)) {
+          have = true;
+          best_axis = axis;
+          best_split = i;
+          best_cost = cost;
+        }
+      }
+    }
+
+    if (have && best_cost < kLeafCost * (double)n) {  // src/bvh.rs:124
+      // Stable partition keeps both sides in ascending sphere order.
+      size_t nl = 0, nr = 0;
+      for (size_t k = lo; k < hi; ++k) {
+        int b = choose_bucket(cmin[best_axis], cmax[best_axis], centroid[best_axis][idx[k]]);
+        if (b < best_split)
+          idx[lo + nl++] = idx[k];
+        else
+          tmp[nr++] = idx[k];
+      }
+      std::copy(tmp.begin(), tmp.begin() + nr, idx.begin() + lo + nl);
+      size_t me = out.nodes.size();
+      out.nodes.push_back(HostNode{box, best_axis, 0, 0, 0});
+      build(lo, lo + nl, depth + 1);
+      out.nodes[me].skip = out.nodes.size() - me;  // src/bvh.rs:126-130
+      build(lo + nl, hi, depth + 1);
+      return;
+    }
+    // Leaf (src/bvh.rs:108-110,137)
+    HostNode leaf{box, 3, 0, out.leaf_indices.size(), n};
+    for (size_t k = lo; k < hi; ++k) out.leaf_indices.push_back(idx[k]);
+    out.nodes.push_back(leaf);
+  }
+};
+
+inline float round_down(double v) {
+  float f = (float)v;
+  if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+  return f;
+}
+inline float round_up(double v) {
+  float f = (float)v;
+  if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+  return f;
+}
+
+}  // namespace
+
+HostBvh build_bvh(const rt_sphere* spheres, size_t n) {
+  Builder b;
+  b.prim_box.resize(n);
+  for (int a = 0; a < 3; ++a) b.centroid[a].resize(n);
+  b.idx.resize(n);
+  b.tmp.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    Box& bx = b.prim_box[i];
+    for (int a = 0; a < 3; ++a) {
+      double p0 = spheres[i].center[a] - spheres[i].radius, p1 = spheres[i].center[a] + spheres[i].radius;
+      bx.min[a] = std::fmin(p0, p1);
+      bx.max[a] = std::fmax(p0, p1);
+      b.centroid[a][i] = bx.min[a] + 0.5 * (bx.max[a] - bx.min[a]);
+    }
+    b.idx[i] = i;
+  }
+  b.out.nodes.reserve(2 * n + 1);
+  b.out.leaf_indices.reserve(n);
+  b.build(0, n, 1);
+  return std::move(b.out);
+}
+
+FlatBvh flatten_bvh(const HostBvh& bvh, const rt_sphere* spheres, size_t n) {
+  FlatBvh f;
+  const size_t nn = bvh.nodes.size();
+  f.nodes.resize(nn);
+  f.spheres.resize(n);
+  f.aux.resize(n);
+
+  // Slots follow the leaves in pre-order, so neighbouring leaves are neighbours in memory.
+  std::vector<uint64_t> slot_of_leaf_first(nn, 0);
+  {
+    size_t slot = 0;
+    for (size_t i = 0; i < nn; ++i) {
+      const HostNode& h = bvh.nodes[i];
+      if (h.kind != 3) continue;
+      slot_of_leaf_first[i] = slot;
+      for (uint64_t k = 0; k < h.count; ++k, ++slot) {
+        uint64_t pi = bvh.leaf_indices[h.first + k];
+        const rt_sphere& s = spheres[pi];
+        f.spheres[slot] = DevSphere{s.center[0], s.center[1], s.center[2], s.radius};
+        f.aux[slot] = DevSphereAux{1.0 / s.radius, s.material, (uint32_t)pi};
+      }
+    }
+  }
+
+  // Breadth-first renumbering.
+  std::vector<uint64_t> order;  // order[new] = old
+  order.reserve(nn);
+  if (nn) order.push_back(0);
+  for (size_t head = 0; head < order.size(); ++head) {
+    uint64_t old = order[head];
+    const HostNode& h = bvh.nodes[old];
+    if (h.kind != 3) {
+      order.push_back(old + 1);
+      order.push_back(old + h.skip);
+    }
+  }
+  std::vector<uint32_t> new_of_old(nn);
+  for (size_t k = 0; k < order.size(); ++k) new_of_old[order[k]] = (uint32_t)k;
+  for (size_t k = 0; k < order.size(); ++k) {
+    const HostNode& h = bvh.nodes[order[k]];
+    DevNode d;
+    for (int a = 0; a < 3; ++a) {
+      d.lo[a] = round_down(h.box.min[a]);
+      d.hi[a] = round_up(h.box.max[a]);
+    }
+    if (h.kind != 3) {
+      d.a = new_of_old[order[k] + 1];
+      d.b = (uint32_t)h.kind;
+    } else {
+      d.a = (uint32_t)slot_of_leaf_first[order[k]];
+      d.b = 0x80000000u | (uint32_t)h.count;
+    }
+    f.nodes[k] = d;
+  }
+  return f;
+}
+
+}  // namespace rta

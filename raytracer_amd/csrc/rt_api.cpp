@@ -1,0 +1,539 @@
+// C ABI of libraytracer_amd.so (declared in include/rt.h): argument checks,
+// device memory, and the sequencing of kernel launches.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bvh_builder.h"
+#include "rt.h"
+#include "rt_host.h"
+#include "rt_launch.h"
+
+using namespace rta;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+  g_error = msg;
+  return code;
+}
+
+#define RT_HIP(call)                                                                                         \
+  do {                                                                                                       \
+    hipError_t e_ = (call);                                                                                  \
+    if (e_ != hipSuccess) return fail(RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+// Frees device allocations when a call leaves early.
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <class T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+struct DeviceGuard {  // makes the scene's device current for the duration of a call
+  int prev = -1;
+  hipError_t status;
+  explicit DeviceGuard(int dev) {
+    status = hipGetDevice(&prev);
+    if (status == hipSuccess && prev != dev) status = hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+const size_t kLdsPerCu = 160 * 1024;
+
+}  // namespace
+
+struct rt_scene {
+  int device = 0;
+  int num_cus = 0;
+  HostBvh host;
+  size_t n_spheres = 0, n_materials = 0;
+  void *d_nodes = nullptr, *d_spheres = nullptr, *d_aux = nullptr, *d_materials = nullptr;
+  SceneDev dev{};
+  rt_scene_info info{};
+};
+
+struct rt_host_bvh {
+  HostBvh bvh;
+};
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+void rt_config_default(rt_config* cfg) {
+  if (cfg) config_default(cfg);
+}
+
+int rt_camera_derive(const rt_config* cfg, rt_camera* out) {
+  if (!cfg || !out) return fail(RT_ERR_INVALID, "rt_camera_derive: null argument");
+  std::string why = config_check(*cfg);
+  if (!why.empty()) return fail(RT_ERR_INVALID, "rt_camera_derive: " + why);
+  camera_derive(*cfg, out);
+  return RT_OK;
+}
+
+int rt_scene_create(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, rt_scene** out) {
+  if (!out) return fail(RT_ERR_INVALID, "rt_scene_create: out is null");
+  *out = nullptr;
+  if ((n && !spheres) || (nm && !materials)) return fail(RT_ERR_INVALID, "rt_scene_create: null array");
+  if (n >= (1ull << 30)) return fail(RT_ERR_LIMIT, "rt_scene_create: at most 2^30-1 spheres");
+  for (size_t i = 0; i < n; ++i) {
+    const rt_sphere& s = spheres[i];
+    for (int k = 0; k < 3; ++k)
+      if (!std::isfinite(s.center[k]) || std::fabs(s.center[k]) > 1e15)
+        return fail(RT_ERR_INVALID, "rt_scene_create: sphere " + std::to_string(i) + " has a non-finite or huge centre");
+    if (!std::isfinite(s.radius) || std::fabs(s.radius) > 1e15 || s.radius == 0.0)
+      return fail(RT_ERR_INVALID, "rt_scene_create: sphere " + std::to_string(i) + " has a zero, non-finite or huge radius");
+    if (s.material >= nm) return fail(RT_ERR_INVALID, "rt_scene_create: sphere " + std::to_string(i) + " names a material out of range");
+  }
+  for (size_t i = 0; i < nm; ++i) {
+    const rt_material& m = materials[i];
+    if (m.type > RT_DIELECTRIC) return fail(RT_ERR_INVALID, "rt_scene_create: material " + std::to_string(i) + " has an unknown type");
+    if (!std::isfinite(m.albedo[0]) || !std::isfinite(m.albedo[1]) || !std::isfinite(m.albedo[2]) || !std::isfinite(m.param))
+      return fail(RT_ERR_INVALID, "rt_scene_create: material " + std::to_string(i) + " has a non-finite field");
+  }
+
+  rt_scene* sc = new (std::nothrow) rt_scene();
+  if (!sc) return fail(RT_ERR_LIMIT, "rt_scene_create: out of host memory");
+  struct Cleanup {
+    rt_scene* s;
+    ~Cleanup() {
+      if (s) rt_scene_destroy(s);
+    }
+  } cleanup{sc};
+
+  RT_HIP(hipGetDevice(&sc->device));
+  hipDeviceProp_t prop;
+  RT_HIP(hipGetDeviceProperties(&prop, sc->device));
+  sc->num_cus = prop.multiProcessorCount;
+
+  auto t0 = std::chrono::steady_clock::now();
+  sc->host = build_bvh(spheres, n);
+  FlatBvh flat = flatten_bvh(sc->host, spheres, n);
+  auto t1 = std::chrono::steady_clock::now();
+  sc->n_spheres = n;
+  sc->n_materials = nm;
+
+  // Material table: 4 x 16 bytes each.
+  std::vector<double> mats(8 * nm, 0.0);
+  for (size_t i = 0; i < nm; ++i) {
+    const rt_material& m = materials[i];
+    double* d = &mats[8 * i];
+    d[0] = m.albedo[0];
+    d[1] = m.albedo[1];
+    d[2] = m.albedo[2];
+    d[3] = m.param;
+    d[4] = 1.0 / m.param;  // Dielectric: ir.powi(-1), src/material.rs:52
+    double r0 = (1.0 - m.param) / (1.0 + m.param);  // Schlick r0, src/material.rs:47-48 (same value for ir and 1/ir up to rounding)
+    d[5] = r0 * r0;
+    uint64_t type = m.type;
+    std::memcpy(&d[6], &type, 8);
+  }
+
+  // LDS plan: the per-lane stacks come first; what is left holds the top of
+  // the tree and, if everything fits, the sphere records.  Two workgroups per
+  // CU when possible.
+  const uint32_t depth = sc->host.depth ? sc->host.depth : 1;
+  const size_t stack_bytes = (size_t)depth * kWorkgroup * 4;
+  size_t per_wg = kLdsPerCu / 2;
+  if (stack_bytes + 16 * 1024 > per_wg) per_wg = kLdsPerCu;
+  if (stack_bytes + 1024 > per_wg)
+    return fail(RT_ERR_LIMIT, "rt_scene_create: BVH depth " + std::to_string(depth) + " needs more traversal stack than LDS holds");
+  const size_t room = per_wg - stack_bytes;
+  const size_t node_bytes = flat.nodes.size() * sizeof(DevNode), sph_bytes = flat.spheres.size() * sizeof(DevSphere);
+  uint32_t n_nodes_lds, n_sph_lds = 0;
+  if (node_bytes + sph_bytes <= room) {
+    n_nodes_lds = (uint32_t)flat.nodes.size();
+    n_sph_lds = (uint32_t)flat.spheres.size();
+  } else {
+    n_nodes_lds = (uint32_t)std::min(flat.nodes.size(), room / sizeof(DevNode));
+  }
+
+  RT_HIP(hipMalloc(&sc->d_nodes, node_bytes ? node_bytes : 32));
+  RT_HIP(hipMalloc(&sc->d_spheres, sph_bytes ? sph_bytes : 32));
+  RT_HIP(hipMalloc(&sc->d_aux, flat.aux.size() ? flat.aux.size() * sizeof(DevSphereAux) : 16));
+  RT_HIP(hipMalloc(&sc->d_materials, nm ? nm * 64 : 64));
+  if (node_bytes) RT_HIP(hipMemcpy(sc->d_nodes, flat.nodes.data(), node_bytes, hipMemcpyHostToDevice));
+  if (sph_bytes) RT_HIP(hipMemcpy(sc->d_spheres, flat.spheres.data(), sph_bytes, hipMemcpyHostToDevice));
+  if (n) RT_HIP(hipMemcpy(sc->d_aux, flat.aux.data(), n * sizeof(DevSphereAux), hipMemcpyHostToDevice));
+  if (nm) RT_HIP(hipMemcpy(sc->d_materials, mats.data(), nm * 64, hipMemcpyHostToDevice));
+
+  sc->dev.nodes = static_cast<const float4*>(sc->d_nodes);
+  sc->dev.spheres = static_cast<const double2*>(sc->d_spheres);
+  sc->dev.aux = static_cast<const double2*>(sc->d_aux);
+  sc->dev.materials = static_cast<const double2*>(sc->d_materials);
+  sc->dev.n_nodes = (uint32_t)flat.nodes.size();
+  sc->dev.n_spheres = (uint32_t)n;
+  sc->dev.n_nodes_lds = n_nodes_lds;
+  sc->dev.n_spheres_lds = n_sph_lds;
+  sc->dev.stack_cap = depth;
+
+  sc->info.n_spheres = n;
+  sc->info.n_nodes = flat.nodes.size();
+  sc->info.depth = sc->host.depth;
+  sc->info.n_nodes_in_lds = n_nodes_lds;
+  sc->info.spheres_in_lds = n_sph_lds ? 1 : 0;
+  sc->info.device = (uint32_t)sc->device;
+  sc->info.device_bytes = node_bytes + sph_bytes + n * sizeof(DevSphereAux) + nm * 64;
+  sc->info.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+
+  cleanup.s = nullptr;
+  *out = sc;
+  return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* sc) {
+  if (!sc) return RT_OK;
+  DeviceGuard g(sc->device);
+  if (sc->d_nodes) (void)hipFree(sc->d_nodes);
+  if (sc->d_spheres) (void)hipFree(sc->d_spheres);
+  if (sc->d_aux) (void)hipFree(sc->d_aux);
+  if (sc->d_materials) (void)hipFree(sc->d_materials);
+  delete sc;
+  return RT_OK;
+}
+
+int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
+  if (!sc || !out) return fail(RT_ERR_INVALID, "rt_scene_get_info: null argument");
+  *out = sc->info;
+  return RT_OK;
+}
+
+static void dump_bvh(const HostBvh& b, double* boxes, int32_t* kind, uint64_t* skip_or_count, uint64_t* leaf_indices) {
+  for (size_t i = 0; i < b.nodes.size(); ++i) {
+    const HostNode& h = b.nodes[i];
+    if (boxes) {
+      std::memcpy(boxes + 6 * i, h.box.min, 24);
+      std::memcpy(boxes + 6 * i + 3, h.box.max, 24);
+    }
+    if (kind) kind[i] = h.kind;
+    if (skip_or_count) skip_or_count[i] = h.kind == 3 ? h.count : h.skip;
+  }
+  if (leaf_indices) std::memcpy(leaf_indices, b.leaf_indices.data(), b.leaf_indices.size() * 8);
+}
+
+int rt_scene_bvh_dump(const rt_scene* sc, double* boxes, int32_t* kind, uint64_t* skip_or_count, uint64_t* leaf_indices) {
+  if (!sc) return fail(RT_ERR_INVALID, "rt_scene_bvh_dump: scene is null");
+  dump_bvh(sc->host, boxes, kind, skip_or_count, leaf_indices);
+  return RT_OK;
+}
+
+int rt_bvh_build(const rt_sphere* spheres, size_t n, rt_host_bvh** out) {
+  if (!out || (n && !spheres)) return fail(RT_ERR_INVALID, "rt_bvh_build: null argument");
+  rt_host_bvh* b = new (std::nothrow) rt_host_bvh();
+  if (!b) return fail(RT_ERR_LIMIT, "rt_bvh_build: out of host memory");
+  b->bvh = build_bvh(spheres, n);
+  *out = b;
+  return RT_OK;
+}
+int rt_bvh_destroy(rt_host_bvh* b) {
+  delete b;
+  return RT_OK;
+}
+int rt_bvh_counts(const rt_host_bvh* b, uint64_t* n_nodes, uint64_t* n_leaf_indices, uint32_t* depth) {
+  if (!b) return fail(RT_ERR_INVALID, "rt_bvh_counts: bvh is null");
+  if (n_nodes) *n_nodes = b->bvh.nodes.size();
+  if (n_leaf_indices) *n_leaf_indices = b->bvh.leaf_indices.size();
+  if (depth) *depth = b->bvh.depth;
+  return RT_OK;
+}
+int rt_bvh_dump(const rt_host_bvh* b, double* boxes, int32_t* kind, uint64_t* skip_or_count, uint64_t* leaf_indices) {
+  if (!b) return fail(RT_ERR_INVALID, "rt_bvh_dump: bvh is null");
+  dump_bvh(b->bvh, boxes, kind, skip_or_count, leaf_indices);
+  return RT_OK;
+}
+
+int rt_trace_batch(const rt_scene* sc, const double* org, const double* dir, size_t n, double t_min, double t_max, int32_t* prim,
+                   double* t, double* normal, uint8_t* front_face) {
+  if (!sc) return fail(RT_ERR_INVALID, "rt_trace_batch: scene is null");
+  if (n == 0) return RT_OK;
+  if (!org || !dir || !prim || !t || !normal || !front_face) return fail(RT_ERR_INVALID, "rt_trace_batch: null buffer");
+  if (std::isnan(t_min) || std::isnan(t_max)) return fail(RT_ERR_INVALID, "rt_trace_batch: NaN interval");
+  DeviceGuard g(sc->device);
+  RT_HIP(g.status);
+  DevBuf d_org, d_dir, d_prim, d_t, d_n, d_f;
+  RT_HIP(d_org.alloc(n * 24));
+  RT_HIP(d_dir.alloc(n * 24));
+  RT_HIP(d_prim.alloc(n * 4));
+  RT_HIP(d_t.alloc(n * 8));
+  RT_HIP(d_n.alloc(n * 24));
+  RT_HIP(d_f.alloc(n));
+  RT_HIP(hipMemcpy(d_org.p, org, n * 24, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(d_dir.p, dir, n * 24, hipMemcpyHostToDevice));
+  RT_HIP(launch_trace_batch(sc->dev, d_org.as<double>(), d_dir.as<double>(), n, t_min, t_max, d_prim.as<int32_t>(), d_t.as<double>(),
+                            d_n.as<double>(), d_f.as<uint8_t>(), nullptr, sc->num_cus * 2, nullptr));
+  RT_HIP(hipDeviceSynchronize());
+  RT_HIP(hipMemcpy(prim, d_prim.p, n * 4, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(t, d_t.p, n * 8, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(normal, d_n.p, n * 24, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(front_face, d_f.p, n, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_scatter_batch(const rt_scene* sc, const uint32_t* material, const double* in_dir, const double* p, const double* normal,
+                     const uint8_t* front_face, const double* u, size_t n, uint8_t* scattered, double* attenuation, double* out_dir) {
+  if (!sc) return fail(RT_ERR_INVALID, "rt_scatter_batch: scene is null");
+  if (n == 0) return RT_OK;
+  if (!material || !in_dir || !p || !normal || !front_face || !u || !scattered || !attenuation || !out_dir)
+    return fail(RT_ERR_INVALID, "rt_scatter_batch: null buffer");
+  for (size_t i = 0; i < n; ++i)
+    if (material[i] >= sc->n_materials) return fail(RT_ERR_INVALID, "rt_scatter_batch: material index out of range");
+  DeviceGuard g(sc->device);
+  RT_HIP(g.status);
+  DevBuf d_m, d_in, d_p, d_n, d_f, d_u, d_s, d_a, d_o;
+  RT_HIP(d_m.alloc(n * 4));
+  RT_HIP(d_in.alloc(n * 24));
+  RT_HIP(d_p.alloc(n * 24));
+  RT_HIP(d_n.alloc(n * 24));
+  RT_HIP(d_f.alloc(n));
+  RT_HIP(d_u.alloc(n * 16));
+  RT_HIP(d_s.alloc(n));
+  RT_HIP(d_a.alloc(n * 24));
+  RT_HIP(d_o.alloc(n * 24));
+  RT_HIP(hipMemcpy(d_m.p, material, n * 4, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(d_in.p, in_dir, n * 24, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(d_p.p, p, n * 24, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(d_n.p, normal, n * 24, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(d_f.p, front_face, n, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(d_u.p, u, n * 16, hipMemcpyHostToDevice));
+  RT_HIP(launch_scatter_batch(sc->dev, d_m.as<uint32_t>(), d_in.as<double>(), d_p.as<double>(), d_n.as<double>(), d_f.as<uint8_t>(),
+                              d_u.as<double>(), n, d_s.as<uint8_t>(), d_a.as<double>(), d_o.as<double>(), nullptr));
+  RT_HIP(hipDeviceSynchronize());
+  RT_HIP(hipMemcpy(scattered, d_s.p, n, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(attenuation, d_a.p, n * 24, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(out_dir, d_o.p, n * 24, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_slab_batch(const double* boxes, const double* org, const double* dir, const double* interval, size_t n, uint8_t* hit) {
+  if (n == 0) return RT_OK;
+  if (!boxes || !org || !dir || !interval || !hit) return fail(RT_ERR_INVALID, "rt_slab_batch: null buffer");
+  // Round the boxes outwards to f32 exactly as scene creation does.
+  std::vector<float> fb(8 * n, 0.0f);
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      double lo = boxes[6 * i + k], hi = boxes[6 * i + 3 + k];
+      float fl = (float)lo, fh = (float)hi;
+      if ((double)fl > lo) fl = std::nextafterf(fl, -INFINITY);
+      if ((double)fh < hi) fh = std::nextafterf(fh, INFINITY);
+      fb[8 * i + k] = fl;
+      fb[8 * i + 4 + k] = fh;
+    }
+  DevBuf d_b, d_o, d_d, d_i, d_h;
+  RT_HIP(d_b.alloc(n * 32));
+  RT_HIP(d_o.alloc(n * 24));
+  RT_HIP(d_d.alloc(n * 24));
+  RT_HIP(d_i.alloc(n * 16));
+  RT_HIP(d_h.alloc(n));
+  RT_HIP(hipMemcpy(d_b.p, fb.data(), n * 32, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(d_o.p, org, n * 24, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(d_d.p, dir, n * 24, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(d_i.p, interval, n * 16, hipMemcpyHostToDevice));
+  RT_HIP(launch_slab_batch(d_b.as<float>(), d_o.as<double>(), d_d.as<double>(), d_i.as<double>(), n, d_h.as<uint8_t>(), nullptr));
+  RT_HIP(hipDeviceSynchronize());
+  RT_HIP(hipMemcpy(hit, d_h.p, n, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+static int make_camera_dev(const rt_config* cfg, CameraDev* cam, const char* who) {
+  if (!cfg) return fail(RT_ERR_INVALID, std::string(who) + ": cfg is null");
+  std::string why = config_check(*cfg);
+  if (!why.empty()) return fail(RT_ERR_INVALID, std::string(who) + ": " + why);
+  rt_camera c;
+  camera_derive(*cfg, &c);
+  std::memcpy(cam->center, c.center, 24);
+  std::memcpy(cam->pixel00, c.pixel00_loc, 24);
+  std::memcpy(cam->du, c.pixel_delta_u, 24);
+  std::memcpy(cam->dv, c.pixel_delta_v, 24);
+  std::memcpy(cam->disk_u, c.defocus_disk_u, 24);
+  std::memcpy(cam->disk_v, c.defocus_disk_v, 24);
+  cam->width = cfg->image_width;
+  cam->height = c.image_height;
+  cam->defocus = cfg->defocus_angle <= 0.0 ? 0u : 1u;  // src/camera.rs:127
+  cam->max_depth = (uint32_t)cfg->max_depth;
+  return RT_OK;
+}
+
+int rt_primary_rays(const rt_config* cfg, uint64_t seed, const uint32_t* ijs, size_t n, double* org, double* dir) {
+  CameraDev cam;
+  int rc = make_camera_dev(cfg, &cam, "rt_primary_rays");
+  if (rc) return rc;
+  if (n == 0) return RT_OK;
+  if (!ijs || !org || !dir) return fail(RT_ERR_INVALID, "rt_primary_rays: null buffer");
+  DevBuf d_i, d_o, d_d;
+  RT_HIP(d_i.alloc(n * 12));
+  RT_HIP(d_o.alloc(n * 24));
+  RT_HIP(d_d.alloc(n * 24));
+  RT_HIP(hipMemcpy(d_i.p, ijs, n * 12, hipMemcpyHostToDevice));
+  RT_HIP(launch_primary_rays(cam, seed, d_i.as<uint32_t>(), n, d_o.as<double>(), d_d.as<double>(), nullptr));
+  RT_HIP(hipDeviceSynchronize());
+  RT_HIP(hipMemcpy(org, d_o.p, n * 24, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(dir, d_d.p, n * 24, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile,
+                     double* rgb_sum_dev, void* stream_, rt_render_stats* stats) {
+  if (!sc) return fail(RT_ERR_INVALID, "rt_render: scene is null");
+  if (!rgb_sum_dev) return fail(RT_ERR_INVALID, "rt_render: rgb_sum is null");
+  RenderParams P{};
+  int rc = make_camera_dev(cfg, &P.cam, "rt_render");
+  if (rc) return rc;
+  if (spp_end < spp_begin) return fail(RT_ERR_INVALID, "rt_render: spp_end < spp_begin");
+  rt_rect r = tile ? *tile : rt_rect{0, 0, P.cam.width, P.cam.height};
+  if (r.x1 > P.cam.width || r.y1 > P.cam.height || r.x0 > r.x1 || r.y0 > r.y1) return fail(RT_ERR_INVALID, "rt_render: tile outside the image");
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  const uint32_t tw = r.x1 - r.x0, th = r.y1 - r.y0, spp = spp_end - spp_begin;
+  if (tw == 0 || th == 0 || spp == 0) return RT_OK;
+
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard g(sc->device);
+  RT_HIP(g.status);
+
+  // Enough work items to fill the chip: split the sample range into chunks
+  // when the tile has few pixels.  The count depends on the request only.
+  const uint64_t kTargetLanes = 1u << 21;
+  uint64_t pixels = (uint64_t)tw * th;
+  uint32_t n_chunks = (uint32_t)std::min<uint64_t>(spp, std::max<uint64_t>(1, (kTargetLanes + pixels - 1) / pixels));
+  uint32_t chunk_spp = (spp + n_chunks - 1) / n_chunks;
+  n_chunks = (spp + chunk_spp - 1) / chunk_spp;
+
+  P.sc = sc->dev;
+  P.x0 = r.x0;
+  P.y0 = r.y0;
+  P.x1 = r.x1;
+  P.y1 = r.y1;
+  P.tiles_x = (tw + 7) / 8;
+  P.n_tiles = P.tiles_x * ((th + 7) / 8);
+  P.n_chunks = n_chunks;
+  P.chunk_spp = chunk_spp;
+  P.spp_begin = spp_begin;
+  P.spp_end = spp_end;
+  P.seed_lo = (uint32_t)seed;
+  P.seed_hi = (uint32_t)(seed >> 32);
+  uint64_t n_items = (uint64_t)P.n_tiles * n_chunks;
+  if (n_items >= 0xffffffffull) return fail(RT_ERR_LIMIT, "rt_render: too many work items; render a smaller tile or sample range");
+  P.n_items = (uint32_t)n_items;
+  P.direct = n_chunks == 1 ? 1u : 0u;
+
+  DevBuf counters, partial;
+  RT_HIP(counters.alloc(3 * 8));
+  RT_HIP(hipMemsetAsync(counters.p, 0, 3 * 8, stream));
+  P.counters = counters.as<unsigned long long>();
+  if (P.direct) {
+    P.out = rgb_sum_dev;
+  } else {
+    RT_HIP(partial.alloc((size_t)n_chunks * pixels * 24));
+    P.out = partial.as<double>();
+  }
+
+  const size_t lds = tree_lds_bytes(sc->dev, kWorkgroup);
+  int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, kLdsPerCu / std::max<size_t>(lds, 1)));
+  int blocks = sc->num_cus * per_cu;
+  uint64_t waves_needed = (n_items + (kWorkgroup / 64) - 1) / (kWorkgroup / 64);
+  if ((uint64_t)blocks > waves_needed) blocks = (int)waves_needed;
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  RT_HIP(hipEventCreate(&ev0));
+  struct EvGuard {
+    hipEvent_t& a;
+    hipEvent_t& b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } evg{ev0, ev1};
+  RT_HIP(hipEventCreate(&ev1));
+  RT_HIP(hipEventRecord(ev0, stream));
+  RT_HIP(launch_render(P, blocks, stream));
+  uint32_t launches = 1;
+  if (!P.direct) {
+    RT_HIP(launch_reduce_chunks(partial.as<double>(), rgb_sum_dev, n_chunks, r.x0, r.y0, tw, th, P.cam.width, stream));
+    ++launches;
+  }
+  RT_HIP(hipEventRecord(ev1, stream));
+
+  // The workspace is freed when this function returns, so the stream must
+  // have drained by then; callers that pass stats want that anyway.
+  RT_HIP(hipStreamSynchronize(stream));
+  if (stats) {
+    unsigned long long c[3];
+    RT_HIP(hipMemcpy(c, counters.p, sizeof(c), hipMemcpyDeviceToHost));
+    float ms = 0.0f;
+    RT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+    stats->rays = c[1];
+    stats->samples = c[2];
+    stats->kernel_ms = ms;
+    stats->launches = launches;
+  }
+  return RT_OK;
+}
+
+int rt_render(const rt_scene* sc, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile,
+              double* rgb_sum, rt_render_stats* stats) {
+  if (!sc) return fail(RT_ERR_INVALID, "rt_render: scene is null");
+  if (!rgb_sum) return fail(RT_ERR_INVALID, "rt_render: rgb_sum is null");
+  CameraDev cam;
+  int rc = make_camera_dev(cfg, &cam, "rt_render");
+  if (rc) return rc;
+  DeviceGuard g(sc->device);
+  RT_HIP(g.status);
+  const size_t n = (size_t)cam.width * cam.height * 3;
+  DevBuf img;
+  RT_HIP(img.alloc(n * 8));
+  RT_HIP(hipMemset(img.p, 0, n * 8));
+  rc = rt_render_device(sc, cfg, seed, spp_begin, spp_end, tile, img.as<double>(), nullptr, stats);
+  if (rc) return rc;
+  std::vector<double> host(n);
+  RT_HIP(hipMemcpy(host.data(), img.p, n * 8, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) rgb_sum[i] += host[i];
+  return RT_OK;
+}
+
+int rt_quantise(const double* rgb_sum, size_t n_pixels, uint64_t spp, uint8_t* out) {
+  if (n_pixels && (!rgb_sum || !out)) return fail(RT_ERR_INVALID, "rt_quantise: null buffer");
+  quantise(rgb_sum, n_pixels, spp, out);
+  return RT_OK;
+}
+
+int rt_write_ppm(int fd, const double* rgb_sum, uint32_t width, uint32_t height, uint64_t spp) {
+  if (!rgb_sum && width && height) return fail(RT_ERR_INVALID, "rt_write_ppm: rgb_sum is null");
+  if (!write_ppm(fd, rgb_sum, width, height, spp)) return fail(RT_ERR_IO, "rt_write_ppm: write failed");
+  return RT_OK;
+}
+
+int rt_scene_rtiow(uint64_t seed, rt_sphere* spheres, rt_material* materials) {
+  if (!spheres || !materials) return fail(RT_ERR_INVALID, "rt_scene_rtiow: null buffer");
+  scene_rtiow(seed, spheres, materials);
+  return RT_OK;
+}
+
+int rt_scene_field(uint64_t seed, size_t n_small, double p_lambertian, double p_metal, double max_fuzz, rt_sphere* spheres,
+                   rt_material* materials) {
+  if (!spheres || !materials) return fail(RT_ERR_INVALID, "rt_scene_field: null buffer");
+  if (!(p_lambertian >= 0.0) || !(p_metal >= 0.0) || p_lambertian + p_metal > 1.0 + 1e-12)
+    return fail(RT_ERR_INVALID, "rt_scene_field: probabilities must be non-negative and sum to at most 1");
+  scene_field(seed, n_small, p_lambertian, p_metal, max_fuzz, spheres, materials);
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,355 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI.
+
+Bars: closest-hit sphere index exact except documented near-ties
+(|dt|/t <= 1e-5), hit distance and normal within 1e-5 relative (observed
+around 1e-14), scatter outputs within 1e-9, renders compared pixel by pixel.
+"""
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5
+
+
+def _oracle_scene(orc, spheres, materials):
+    return orc.Scene(spheres.view(orc.SPHERE_DTYPE), materials.view(orc.MATERIAL_DTYPE))
+
+
+@pytest.fixture(scope="module")
+def rtiow():
+    return rt.scene_rtiow(1)
+
+
+@pytest.fixture(scope="module")
+def world(rtiow):
+    w = rt.BVH(*rtiow)
+    yield w
+    w.close()
+
+
+@pytest.fixture(scope="module")
+def oworld(oracle, rtiow):
+    return _oracle_scene(oracle, *rtiow)
+
+
+def compare_hits(got, want, org=None):
+    """Returns the number of near-tie index mismatches after asserting the bars."""
+    gp, wp = got["prim"], want["prim"]
+    differ = gp != wp
+    # A different sphere is acceptable only when both found a hit at the same distance.
+    if differ.any():
+        both = (gp >= 0) & (wp >= 0)
+        assert (both | ~differ).all(), "hit/miss disagreement at %s" % np.nonzero(differ & ~both)[0][:10]
+        dt = np.abs(got["t"][differ] - want["t"][differ]) / np.abs(want["t"][differ])
+        assert (dt <= REL).all(), "index mismatch that is not a near-tie: rel dt %s" % dt.max()
+    hit = (wp >= 0) & ~differ
+    assert np.array_equal(got["t"][~hit & ~differ], want["t"][~hit & ~differ])  # +inf on misses
+    rel_t = np.abs(got["t"][hit] - want["t"][hit]) / np.abs(want["t"][hit])
+    assert rel_t.size == 0 or rel_t.max() <= REL
+    assert np.array_equal(got["front"][hit], want["front"][hit])
+    dn = np.abs(got["normal"][hit] - want["normal"][hit])
+    assert dn.size == 0 or dn.max() <= REL
+    return int(differ.sum()), (rel_t.max() if rel_t.size else 0.0), (dn.max() if dn.size else 0.0)
+
+
+def test_library_loaded_is_in_tree():
+    import os
+
+    assert os.path.exists(rt.LIB_PATH)
+    assert rt._lib.lib() is not None
+
+
+def test_scene_layout(world):
+    info = world.info()
+    assert info["n_spheres"] == 488 and info["n_nodes"] == 975 and info["depth"] == 13
+    assert info["n_nodes_in_lds"] == 975 and info["spheres_in_lds"] == 1
+
+
+def test_device_bvh_equals_oracle_bvh(world, oworld):
+    for a, b in zip(world.dump(), oworld.bvh_dump()):
+        assert np.array_equal(a, b)
+
+
+def test_primary_rays_match_oracle(oracle):
+    cfg = rt.config_rtiow()
+    cam = cfg.camera()
+    rng = np.random.default_rng(5)
+    ijs = np.stack([rng.integers(0, 830, 4096), rng.integers(0, cam.image_height, 4096), rng.integers(0, 750, 4096)], axis=1)
+    org, d = cam.primary_rays(ijs, seed=12345)
+    oorg, od = oracle.primary_rays(cfg.record().view(oracle.CONFIG_DTYPE), 12345, ijs)
+    assert np.abs(org - oorg).max() <= 1e-12
+    assert np.abs(d - od).max() <= 1e-12
+    # without defocus the origin is the camera centre exactly
+    cfg0 = cfg.defocus_angle(0.0)
+    org0, d0 = cfg0.camera().primary_rays(ijs[:64], seed=1)
+    assert (org0 == np.array([13.0, 2.0, 3.0])).all()
+    oorg0, od0 = oracle.primary_rays(cfg0.record().view(oracle.CONFIG_DTYPE), 1, ijs[:64])
+    assert np.abs(d0 - od0).max() <= 1e-12
+
+
+def test_trace_primary_rays(world, oworld, oracle):
+    cfg = rt.config_rtiow()
+    rng = np.random.default_rng(6)
+    n = 1 << 16
+    ijs = np.stack([rng.integers(0, 830, n), rng.integers(0, 466, n), rng.integers(0, 750, n)], axis=1)
+    org, d = oracle.primary_rays(cfg.record().view(oracle.CONFIG_DTYPE), 12345, ijs)
+    got = world.trace_batch(org, d)
+    want = oworld.trace_batch(org, d)
+    ties, rel_t, dn = compare_hits(got, want)
+    print("primary: %d rays, %d near-tie index differences, max rel dt %.2e, max dn %.2e" % (n, ties, rel_t, dn))
+    assert ties <= n // 1000
+    assert (want["prim"] >= 0).mean() > 0.5
+
+
+def test_trace_reference_regression_ray(world, oworld):
+    # The ray of the reference's test_ray_aabb_intersection_failure (src/aabb.rs:180-194) is a primary ray of this camera.
+    org = [[13.0, 2.0, 3.0]]
+    d = [[-0.99999581369879142, -0.0022009767150356608, -0.001878373336654929]]
+    compare_hits(world.trace_batch(org, d), oworld.trace_batch(org, d))
+
+
+def _secondary_rays(spheres, rng, n):
+    """Rays leaving sphere surfaces in random directions (what scatter produces)."""
+    k = rng.integers(0, len(spheres), n)
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    p = spheres["center"][k] + spheres["radius"][k, None] * u
+    v = rng.normal(size=(n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return p, v
+
+
+def test_trace_secondary_rays(world, oworld, rtiow):
+    rng = np.random.default_rng(7)
+    org, d = _secondary_rays(rtiow[0][1:], rng, 1 << 16)  # small and medium spheres
+    got, want = world.trace_batch(org, d), oworld.trace_batch(org, d)
+    ties, rel_t, dn = compare_hits(got, want)
+    print("secondary: %d near-tie index differences, max rel dt %.2e, max dn %.2e" % (ties, rel_t, dn))
+    assert ties <= 64
+
+
+def test_trace_adversarial_rays(world, oworld, rtiow):
+    rng = np.random.default_rng(8)
+    spheres = rtiow[0]
+    n = 1 << 14
+    # grazing the ground sphere: from just above the ground, nearly horizontal
+    org_g = np.stack([rng.uniform(-11, 11, n), rng.uniform(1e-6, 0.5, n), rng.uniform(-11, 11, n)], axis=1)
+    d_g = np.stack([rng.normal(size=n), rng.uniform(-1e-3, 1e-3, n), rng.normal(size=n)], axis=1)
+    # near-tangent to small spheres: aim at a point at distance r*(1 +- eps) from the centre
+    k = rng.integers(4, len(spheres), n)
+    c, r = spheres["center"][k], spheres["radius"][k]
+    org_t = np.array([13.0, 2.0, 3.0]) + rng.normal(size=(n, 3)) * 0.01
+    to_c = c - org_t
+    side = np.cross(to_c, rng.normal(size=(n, 3)))
+    side /= np.linalg.norm(side, axis=1, keepdims=True)
+    eps = rng.choice([-1e-9, -1e-12, 0.0, 1e-12, 1e-9], n)
+    d_t = (c + side * (r * (1.0 + eps))[:, None]) - org_t
+    # axis-parallel and zero-component directions
+    org_a = rng.uniform(-5, 5, (n, 3)) + np.array([0.0, 6.0, 0.0])
+    d_a = np.zeros((n, 3))
+    d_a[np.arange(n), rng.integers(0, 3, n)] = rng.choice([-1.0, 1.0], n)
+    d_a[: n // 2, 0] += rng.normal(size=n // 2) * (d_a[: n // 2, 0] == 0)
+    # rays starting inside spheres
+    k2 = rng.integers(1, len(spheres), n)
+    org_i = spheres["center"][k2] + rng.uniform(-0.5, 0.5, (n, 3)) * spheres["radius"][k2, None]
+    d_i = rng.normal(size=(n, 3))
+    org = np.concatenate([org_g, org_t, org_a, org_i])
+    d = np.concatenate([d_g, d_t, d_a, d_i])
+    got, want = world.trace_batch(org, d), oworld.trace_batch(org, d)
+    ties, rel_t, dn = compare_hits(got, want)
+    print("adversarial: %d near-tie index differences, max rel dt %.2e, max dn %.2e" % (ties, rel_t, dn))
+
+
+def test_trace_interval_arguments(world, oworld, rtiow):
+    rng = np.random.default_rng(9)
+    org, d = _secondary_rays(rtiow[0][1:], rng, 4096)
+    for t_min, t_max in [(1e-3, 5.0), (0.5, 2.0), (1e-6, np.inf), (3.0, 3.0)]:  # origins lie on surfaces, so t_min stays clear of 0
+        compare_hits(world.trace_batch(org, d, t_min, t_max), oworld.trace_batch(org, d, t_min, t_max))
+
+
+def test_slab_test_never_misses_where_reference_hits(oracle):
+    rng = np.random.default_rng(10)
+    n = 1 << 18
+    lo = rng.uniform(-20, 20, (n, 3))
+    size = rng.uniform(0, 1, (n, 3)) ** 3 * 20
+    boxes = np.concatenate([lo, lo + size], axis=1)
+    org = rng.uniform(-30, 30, (n, 3))
+    target = lo + size * rng.uniform(-0.2, 1.2, (n, 3))  # aim near the box so that many rays graze faces and edges
+    d = target - org
+    d[rng.random(n) < 0.05, rng.integers(0, 3)] = 0.0
+    tmax = np.where(rng.random(n) < 0.5, np.inf, rng.uniform(0, 80, n))
+    interval = np.stack([np.full(n, 1e-3), tmax], axis=1)
+    want = oracle.slab_batch(boxes, org, d, interval)
+    got = rt.slab_batch(boxes, org, d, interval)
+    assert not (want & ~got).any(), "device culled a node the reference enters"
+    # A zero direction component makes that axis unconstrained on the device (conservative), so
+    # the over-acceptance rate is judged on the other rays only.
+    generic = (d != 0.0).all(axis=1)
+    extra = (got & ~want)[generic].mean()
+    print("slab: reference hits %.3f, device-only hits %.6f (generic rays), %.4f (with a zero component)"
+          % (want.mean(), extra, (got & ~want)[~generic].mean()))
+    assert extra < 1e-3
+
+
+def test_slab_reference_kats():
+    import json
+    import math
+    import os
+
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+    c = G["ray_aabb_intersection"]
+    box = np.array([100.0, 100.0, 100.0, 105.0, 105.0, 105.0])
+    for case in c["cases"]:
+        assert rt.slab_batch([box], [c["origin"]], [c["direction"]], [case["interval"]])[0] == case["some"]
+    s = math.sqrt(1.0 / 3.0)
+    for case in G["ray_aabb_intersection_angle"]["cases"]:
+        assert rt.slab_batch([[0, 0, 0, s, s, s]], [[-s, -s, -s]], [[1.0, 1.0, 1.0]], [case["interval"]])[0] == case["some"]
+    c = G["ray_aabb_intersection_failure"]
+    assert not rt.slab_batch([[-5.0, 0.0, -1.0, 5.0, 2.0, 1.0]], [c["origin"]], [c["direction"]], [[1e-3, np.inf]])[0]
+
+
+def test_scatter_matches_oracle(world, oracle, rtiow):
+    rng = np.random.default_rng(11)
+    spheres, materials = rtiow
+    n = 3 * 4096
+    by_type = [np.nonzero(materials["type"] == k)[0] for k in range(3)]
+    mat = np.concatenate([rng.choice(ix, n // 3) for ix in by_type]).astype(np.uint32)
+    normal = rng.normal(size=(n, 3))
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    in_dir = rng.normal(size=(n, 3))
+    # HitRecord::new makes the normal face the incoming ray (src/hit.rs:19-23)
+    flip = (in_dir * normal).sum(axis=1) > 0
+    normal[flip] *= -1
+    front = rng.random(n) < 0.5
+    p = rng.uniform(-10, 10, (n, 3))
+    u = rng.random((n, 2))
+    # grazing incidence exercises total internal reflection
+    in_dir[::7] = in_dir[::7] - 0.98 * (in_dir[::7] * normal[::7]).sum(axis=1, keepdims=True) * normal[::7]
+    gs, ga, gd = world.scatter_batch(mat, in_dir, p, normal, front, u)
+    ws, wa, wd = oracle.scatter_batch(materials.view(oracle.MATERIAL_DTYPE), mat, in_dir, p, normal, front, u)
+    assert np.array_equal(gs, ws)
+    assert np.abs(ga - wa).max() <= 1e-12
+    assert np.abs(gd - wd).max() <= 1e-9
+    assert (~ws).sum() > 0  # some metal rays are absorbed
+    print("scatter: max |d attenuation| %.2e, max |d direction| %.2e, absorbed %d" % (np.abs(ga - wa).max(), np.abs(gd - wd).max(), (~ws).sum()))
+
+
+def _pixel_agreement(got, want, tol=1e-9):
+    diff = np.abs(got - want).max(axis=2)
+    scale = np.maximum(1.0, np.abs(want).max(axis=2))
+    return (diff <= tol * scale).mean(), diff.max()
+
+
+def test_render_matches_oracle_small(world, oworld, oracle):
+    cfg = rt.config_rtiow(image_width=96, samples_per_pixel=8, max_depth=50)
+    cam = cfg.camera()
+    got, stats = cam.render_sum(world, seed=12345)
+    want, ostats = oworld.render(cfg.record().view(oracle.CONFIG_DTYPE), 12345, 0, 8, nthreads=8)
+    frac, worst = _pixel_agreement(got, want)
+    print("render 96x54x8: %.2f%% pixels equal to 1e-9, worst |diff| %.3e, rays gpu %d oracle %d" % (100 * frac, worst, stats["rays"], ostats[0]))
+    # Paths are chaotic: a last-bit difference can send a deep path elsewhere, so a few pixels may differ by one sample.
+    assert frac >= 0.97
+    assert abs(stats["rays"] - int(ostats[0])) <= 0.002 * int(ostats[0])
+    assert stats["samples"] == 96 * cam.image_height * 8
+    q_got, q_want = rt.quantise(got, 8), oracle.quantise(want, 8)
+    assert (q_got != q_want).any(axis=1).mean() <= 0.03
+    mse = ((q_got.astype(float) - q_want.astype(float)) ** 2).mean()
+    assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) >= 40.0
+
+
+def test_render_tiles_and_sample_ranges_compose(world):
+    cfg = rt.config_rtiow(image_width=64, samples_per_pixel=6, max_depth=20)
+    cam = cfg.camera()
+    h = cam.image_height
+    full, _ = cam.render_sum(world, seed=3)
+    # tiles: disjoint rectangles (not multiples of 8) reproduce the full frame exactly
+    tiled = np.zeros_like(full)
+    for tile in [(0, 0, 29, 17), (29, 0, 64, 17), (0, 17, 64, h)]:
+        cam.render_sum(world, seed=3, tile=tile, rgb_sum=tiled)
+    assert np.array_equal(tiled, full)
+    # sample ranges: same paths, sums differ only by the order of additions
+    split = np.zeros_like(full)
+    cam.render_sum(world, seed=3, spp_begin=0, spp_end=2, rgb_sum=split)
+    cam.render_sum(world, seed=3, spp_begin=2, spp_end=6, rgb_sum=split)
+    assert np.abs(split - full).max() <= 1e-12 * max(1.0, np.abs(full).max())
+    # determinism
+    again, _ = cam.render_sum(world, seed=3)
+    assert np.array_equal(again, full)
+    other, _ = cam.render_sum(world, seed=4)
+    assert not np.array_equal(other, full)
+
+
+def test_render_chunked_equals_unchunked_paths(world):
+    # A small tile with many samples is split into sample chunks internally; a large one is not.
+    cfg = rt.config_rtiow(image_width=32, samples_per_pixel=64, max_depth=10)
+    cam = cfg.camera()
+    a, _ = cam.render_sum(world, seed=9)
+    b = np.zeros_like(a)
+    for s in range(0, 64, 16):
+        cam.render_sum(world, seed=9, spp_begin=s, spp_end=s + 16, rgb_sum=b)
+    assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(a).max())
+
+
+def test_edge_cases(oracle):
+    cfg = rt.Config().image_width(16).samples_per_pixel(2).max_depth(5)
+    cam = cfg.camera()
+    ocfg = cfg.record().view(oracle.CONFIG_DTYPE)
+    # empty scene: every ray sees the sky (src/bvh.rs:51-53)
+    sp = np.zeros(0, dtype=rt.SPHERE_DTYPE)
+    mt = np.zeros(0, dtype=rt.MATERIAL_DTYPE)
+    w = rt.BVH(sp, mt)
+    out = w.trace_batch([[0, 0, 0]], [[0, 0, 1]])
+    assert out["prim"][0] == -1 and np.isinf(out["t"][0])
+    got, stats = cam.render_sum(w, seed=1)
+    want, _ = oracle.Scene(sp.view(oracle.SPHERE_DTYPE), mt.view(oracle.MATERIAL_DTYPE)).render(ocfg, 1, 0, 2)
+    assert np.abs(got - want).max() <= 1e-12
+    assert stats["rays"] == 16 * cam.image_height * 2
+    w.close()
+    # one sphere, each material; max_depth 0 gives black
+    for m in [rt.Lambertian((0.8, 0.3, 0.3)), rt.Metal((0.8, 0.8, 0.8), 0.3), rt.Dielectric(1.5)]:
+        w = rt.BVH([rt.Sphere((0, 0, 1), 0.5, m)])
+        got, _ = cam.render_sum(w, seed=2)
+        want, _ = oracle.Scene(w.spheres.view(oracle.SPHERE_DTYPE), w.materials.view(oracle.MATERIAL_DTYPE)).render(ocfg, 2, 0, 2)
+        assert np.abs(got - want).max() <= 1e-9
+        black, st = cfg.max_depth(0).camera().render_sum(w, seed=2)
+        assert not black.any() and st["rays"] == 0
+        w.close()
+    # a negative radius flips the normal (hollow-glass trick)
+    w = rt.BVH([rt.Sphere((0, 0, 1), -0.5, rt.Dielectric(1.5))])
+    ow = oracle.Scene(w.spheres.view(oracle.SPHERE_DTYPE), w.materials.view(oracle.MATERIAL_DTYPE))
+    compare_hits(w.trace_batch([[0, 0, -1]], [[0, 0.1, 1]]), ow.trace_batch([[0, 0, -1]], [[0, 0.1, 1]]))
+    w.close()
+
+
+def test_errors_are_reported_not_raised_across_the_abi():
+    sp, mt = rt.scene_rtiow(1)
+    bad = sp.copy()
+    bad["center"][3, 1] = np.nan
+    with pytest.raises(rt.RtError) as e:
+        rt.BVH(bad, mt)
+    assert e.value.code == 1 and "sphere 3" in str(e.value)
+    bad = sp.copy()
+    bad["material"][0] = 9999
+    with pytest.raises(rt.RtError):
+        rt.BVH(bad, mt)
+    w = rt.BVH(sp, mt)
+    with pytest.raises(rt.RtError):
+        rt.config_rtiow(image_width=0).camera()
+    cam = rt.config_rtiow(image_width=32).camera()
+    with pytest.raises(rt.RtError):
+        cam.render_sum(w, tile=(0, 0, 64, 4))
+    w.close()
+
+
+def test_hit_and_classes_mirror_reference_usage():
+    ground = rt.Lambertian().albedo((0.5, 0.5, 0.5))
+    objects = [rt.Sphere((0.0, -1000.0, 0.0), 1000.0, ground), rt.Sphere((0.0, 1.0, 0.0), 1.0, rt.Dielectric().ir(1.5))]
+    world = rt.BVH.new(objects)
+    hr = world.hit(rt.Ray.new((0.0, 1.0, -5.0), (0.0, 0.0, 2.0)), rt.Interval(1e-3, float("inf")))
+    assert hr is not None and hr.prim == 1 and hr.front_face
+    assert abs(hr.t - 4.0) < 1e-12 and np.abs(hr.normal - [0, 0, -1]).max() < 1e-12
+    assert world.hit(rt.Ray.new((0.0, 5.0, -5.0), (0.0, 1.0, 0.0)), rt.Interval(1e-3, float("inf"))) is None
+    world.close()
