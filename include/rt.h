@@ -95,17 +95,21 @@ typedef struct rt_render_stats {
   uint64_t samples;     /* camera paths started */
   float kernel_ms;      /* device time of the launch(es) of this call */
   uint32_t launches;    /* kernels launched by this call */
+  uint64_t node_steps;  /* inner nodes visited (two child boxes tested at each) */
+  uint64_t sphere_tests; /* Sphere::hit evaluations */
 } rt_render_stats;
 
 typedef struct rt_scene_info {
   uint64_t n_spheres;
-  uint64_t n_nodes;
+  uint64_t n_nodes;         /* nodes of the host tree (splits + leaves) */
+  uint64_t n_device_nodes;  /* 64-byte device nodes (one per split) */
   uint32_t depth;           /* levels in the BVH (a single leaf has depth 1) */
   uint32_t n_nodes_in_lds;  /* nodes of the top of the tree staged in LDS by the kernels */
-  uint32_t spheres_in_lds;  /* 1 when the sphere records are staged in LDS too */
+  uint32_t spheres_in_lds;  /* bit 0: sphere records staged in LDS too; bit 1: their shading data; bit 2: the materials */
   uint32_t device;          /* HIP device ordinal the scene lives on */
   uint64_t device_bytes;    /* HBM held by the scene */
   double build_ms;          /* host BVH build + flatten */
+  uint64_t lds_bytes;       /* LDS each workgroup of the tree-walking kernels uses for this scene */
 } rt_scene_info;
 
 typedef struct rt_scene rt_scene;
@@ -188,6 +192,11 @@ int rt_render(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32
               double* rgb_sum, rt_render_stats* stats);
 int rt_render_device(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
                      const rt_rect* tile, double* rgb_sum_dev, void* stream, rt_render_stats* stats);
+
+/* Tuning knobs for experiments; not part of the stable interface.  Known names:
+ * "inner_min" (lanes of 64 that must want the inner-node block for a wave to run
+ * it without counting the other blocks; it never changes results). */
+int rt_debug_set(const char* name, double value);
 
 /* `write_colour` (src/camera.rs:85-95) for n pixels: out is n x 3 bytes. Host only. */
 int rt_quantise(const double* rgb_sum, size_t n_pixels, uint64_t samples_per_pixel, uint8_t* out);

@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libraytracer_amd.so")
+# RAYTRACER_AMD_LIB names another build of the same library (used to compare kernel variants in one run).
+LIB_PATH = os.environ.get("RAYTRACER_AMD_LIB") or os.path.join(_HERE, "libraytracer_amd.so")
 
 SPHERE_DTYPE = np.dtype([("center", "<f8", 3), ("radius", "<f8"), ("material", "<u4"), ("reserved", "<u4")])
 MATERIAL_DTYPE = np.dtype([("type", "<u4"), ("reserved", "<u4"), ("albedo", "<f8", 3), ("param", "<f8")])
@@ -40,17 +41,20 @@ CAMERA_DTYPE = np.dtype(
     ]
 )
 RECT_DTYPE = np.dtype([("x0", "<u4"), ("y0", "<u4"), ("x1", "<u4"), ("y1", "<u4")])
-RENDER_STATS_DTYPE = np.dtype([("rays", "<u8"), ("samples", "<u8"), ("kernel_ms", "<f4"), ("launches", "<u4")])
+RENDER_STATS_DTYPE = np.dtype([("rays", "<u8"), ("samples", "<u8"), ("kernel_ms", "<f4"), ("launches", "<u4"), ("node_steps", "<u8"),
+                               ("sphere_tests", "<u8")])
 SCENE_INFO_DTYPE = np.dtype(
     [
         ("n_spheres", "<u8"),
         ("n_nodes", "<u8"),
+        ("n_device_nodes", "<u8"),
         ("depth", "<u4"),
         ("n_nodes_in_lds", "<u4"),
         ("spheres_in_lds", "<u4"),
         ("device", "<u4"),
         ("device_bytes", "<u8"),
         ("build_ms", "<f8"),
+        ("lds_bytes", "<u8"),
     ]
 )
 
@@ -75,6 +79,7 @@ EXPORTS = [
     "rt_primary_rays",
     "rt_render",
     "rt_render_device",
+    "rt_debug_set",
     "rt_quantise",
     "rt_write_ppm",
     "rt_scene_rtiow",

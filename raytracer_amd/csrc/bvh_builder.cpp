@@ -171,60 +171,120 @@ HostBvh build_bvh(const rt_sphere* spheres, size_t n) {
   return std::move(b.out);
 }
 
+namespace {
+
+// The host tree with leaves of more than kMaxLeafCount spheres cut into chains
+// of smaller leaves under extra splits that keep the leaf's box.  (Such leaves
+// only arise when many spheres share one centre.)  Spheres keep their order
+// for rays with a non-negative x direction.
+struct Work {
+  struct N {
+    Box box;
+    int32_t kind;        // 0..2 split, 3 leaf
+    int64_t left, right; // split: child indices in `nodes`
+    uint64_t first, count;  // leaf: slot range
+  };
+  std::vector<N> nodes;
+  int64_t add_leaf_range(const Box& box, uint64_t first, uint64_t count) {
+    if (count <= kMaxLeafCount) {
+      nodes.push_back(N{box, 3, -1, -1, first, count});
+      return (int64_t)nodes.size() - 1;
+    }
+    uint64_t half = count / 2;
+    int64_t me = (int64_t)nodes.size();
+    nodes.push_back(N{box, 0, -1, -1, 0, 0});
+    int64_t l = add_leaf_range(box, first, half);
+    int64_t r = add_leaf_range(box, first + half, count - half);
+    nodes[me].left = l;
+    nodes[me].right = r;
+    return me;
+  }
+};
+
+}  // namespace
+
 FlatBvh flatten_bvh(const HostBvh& bvh, const rt_sphere* spheres, size_t n) {
   FlatBvh f;
   const size_t nn = bvh.nodes.size();
-  f.nodes.resize(nn);
   f.spheres.resize(n);
   f.aux.resize(n);
 
   // Slots follow the leaves in pre-order, so neighbouring leaves are neighbours in memory.
-  std::vector<uint64_t> slot_of_leaf_first(nn, 0);
+  Work w;
+  std::vector<int64_t> work_of_host(nn, -1);
   {
-    size_t slot = 0;
+    uint64_t slot = 0;
+    // Pre-order array: children of a split at i are i+1 and i+skip; build bottom-up by walking backwards.
     for (size_t i = 0; i < nn; ++i) {
       const HostNode& h = bvh.nodes[i];
       if (h.kind != 3) continue;
-      slot_of_leaf_first[i] = slot;
-      for (uint64_t k = 0; k < h.count; ++k, ++slot) {
+      for (uint64_t k = 0; k < h.count; ++k) {
         uint64_t pi = bvh.leaf_indices[h.first + k];
         const rt_sphere& s = spheres[pi];
-        f.spheres[slot] = DevSphere{s.center[0], s.center[1], s.center[2], s.radius};
-        f.aux[slot] = DevSphereAux{1.0 / s.radius, s.material, (uint32_t)pi};
+        f.spheres[slot + k] = DevSphere{s.center[0], s.center[1], s.center[2], s.radius};
+        f.aux[slot + k] = DevSphereAux{1.0 / s.radius, s.material, (uint32_t)pi};
       }
+      work_of_host[i] = w.add_leaf_range(h.box, slot, h.count);
+      slot += h.count;
     }
+    for (size_t i = nn; i-- > 0;) {
+      const HostNode& h = bvh.nodes[i];
+      if (h.kind == 3) continue;
+      w.nodes.push_back(Work::N{h.box, h.kind, work_of_host[i + 1], work_of_host[i + h.skip], 0, 0});
+      work_of_host[i] = (int64_t)w.nodes.size() - 1;
+    }
+  }
+  if (nn == 0 || (bvh.nodes[0].kind == 3 && bvh.nodes[0].count == 0)) return f;  // empty scene: root stays kRefNone
+
+  auto leaf_ref = [](const Work::N& x) { return kRefLeaf | ((uint32_t)x.count << 24) | (uint32_t)x.first; };
+  const int64_t root = work_of_host[0];
+  {
+    const Box& b = w.nodes[root].box;
+    double m = 0.0;
+    for (int a = 0; a < 3; ++a) m = std::fmax(m, std::fmax(std::fabs(b.min[a]), std::fabs(b.max[a])));
+    f.bound = round_up(m);
+  }
+  if (w.nodes[root].kind == 3) {
+    f.root = leaf_ref(w.nodes[root]);
+    f.depth = 1;
+    return f;
   }
 
-  // Breadth-first renumbering.
-  std::vector<uint64_t> order;  // order[new] = old
-  order.reserve(nn);
-  if (nn) order.push_back(0);
+  // Breadth-first numbering of the inner nodes.
+  std::vector<int64_t> order{root};
+  std::vector<uint32_t> level{1};
+  std::vector<uint32_t> new_of(w.nodes.size(), 0);
   for (size_t head = 0; head < order.size(); ++head) {
-    uint64_t old = order[head];
-    const HostNode& h = bvh.nodes[old];
-    if (h.kind != 3) {
-      order.push_back(old + 1);
-      order.push_back(old + h.skip);
-    }
+    const Work::N& x = w.nodes[order[head]];
+    new_of[order[head]] = (uint32_t)head;
+    f.depth = std::max(f.depth, level[head]);
+    for (int64_t c : {x.left, x.right})
+      if (w.nodes[c].kind != 3) {
+        order.push_back(c);
+        level.push_back(level[head] + 1);
+      }
   }
-  std::vector<uint32_t> new_of_old(nn);
-  for (size_t k = 0; k < order.size(); ++k) new_of_old[order[k]] = (uint32_t)k;
+  // new_of for nodes later in `order` is assigned when they are reached; fill all first.
+  for (size_t k = 0; k < order.size(); ++k) new_of[order[k]] = (uint32_t)k;
+  f.nodes.resize(order.size());
   for (size_t k = 0; k < order.size(); ++k) {
-    const HostNode& h = bvh.nodes[order[k]];
-    DevNode d;
-    for (int a = 0; a < 3; ++a) {
-      d.lo[a] = round_down(h.box.min[a]);
-      d.hi[a] = round_up(h.box.max[a]);
+    const Work::N& x = w.nodes[order[k]];
+    DevNode d{};
+    const Work::N* ch[2] = {&w.nodes[x.left], &w.nodes[x.right]};
+    for (int c = 0; c < 2; ++c) {
+      d.x[2 * c] = round_down(ch[c]->box.min[0]);
+      d.x[2 * c + 1] = round_up(ch[c]->box.max[0]);
+      d.y[2 * c] = round_down(ch[c]->box.min[1]);
+      d.y[2 * c + 1] = round_up(ch[c]->box.max[1]);
+      d.z[2 * c] = round_down(ch[c]->box.min[2]);
+      d.z[2 * c + 1] = round_up(ch[c]->box.max[2]);
     }
-    if (h.kind != 3) {
-      d.a = new_of_old[order[k] + 1];
-      d.b = (uint32_t)h.kind;
-    } else {
-      d.a = (uint32_t)slot_of_leaf_first[order[k]];
-      d.b = 0x80000000u | (uint32_t)h.count;
-    }
+    d.ref0 = ch[0]->kind == 3 ? leaf_ref(*ch[0]) : new_of[x.left];
+    d.ref1 = ch[1]->kind == 3 ? leaf_ref(*ch[1]) : new_of[x.right];
+    d.axis = (uint32_t)x.kind;
     f.nodes[k] = d;
   }
+  f.root = 0;
   return f;
 }
 

@@ -33,18 +33,22 @@ struct HostBvh {
 // only.  O(n) work per node instead of the reference's O(31 n) set rebuilds.
 HostBvh build_bvh(const rt_sphere* spheres, size_t n);
 
-// 32-byte device node: two 16-byte words.
-//   lo.xyz / hi.xyz : f32 box, rounded outwards from the f64 box
-//   a : split -> index of the left child (the right child is a+1)
-//       leaf  -> first sphere slot
-//   b : split -> axis (0..2);  leaf -> 0x80000000 | sphere count
+// 64-byte device node: one per inner node of the host tree, holding the f32
+// boxes of both children (rounded outwards from the f64 boxes) as four
+// 16-byte words:
+//   x = (lo0.x, hi0.x, lo1.x, hi1.x), y and z likewise,
+//   ref0, ref1 : child references, axis : split axis (0..2)
+// A reference is the index of an inner node (bit 31 clear) or a leaf:
+// bit 31 set, bits 30..24 sphere count (1..127), bits 23..0 first sphere slot.
 struct DevNode {
-  float lo[3];
-  uint32_t a;
-  float hi[3];
-  uint32_t b;
+  float x[4], y[4], z[4];
+  uint32_t ref0, ref1, axis, pad;
 };
-static_assert(sizeof(DevNode) == 32, "DevNode must be 32 bytes");
+static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
+constexpr uint32_t kRefLeaf = 0x80000000u;
+constexpr uint32_t kRefNone = 0xffffffffu;
+constexpr uint32_t kMaxLeafCount = 127;
+constexpr uint32_t kMaxSlots = 0x00fffff0u;  // slots stay below this so that no leaf ref collides with the kernels' reserved values (0xfffffffd and up)
 
 // Sphere record in leaf order ("slot" order): 32 bytes, f64.
 struct DevSphere {
@@ -65,9 +69,12 @@ struct DevMaterial {
 static_assert(sizeof(DevMaterial) == 48, "DevMaterial must be 48 bytes");
 
 struct FlatBvh {
-  std::vector<DevNode> nodes;  // breadth-first: any prefix is the top of the tree, siblings adjacent
+  std::vector<DevNode> nodes;  // inner nodes, breadth-first: any prefix is the top of the tree
   std::vector<DevSphere> spheres;
   std::vector<DevSphereAux> aux;
+  uint32_t root = kRefNone;  // reference of the root (a leaf reference when the tree is a single leaf)
+  uint32_t depth = 0;        // pushes a traversal can have outstanding, at most
+  float bound = 0.0f;        // largest |coordinate| of any box plane
 };
 
 FlatBvh flatten_bvh(const HostBvh& bvh, const rt_sphere* spheres, size_t n);

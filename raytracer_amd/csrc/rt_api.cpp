@@ -2,9 +2,11 @@
 // device memory, and the sequencing of kernel launches.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -57,7 +59,8 @@ struct DeviceGuard {  // makes the scene's device current for the duration of a 
   }
 };
 
-const size_t kLdsPerCu = 160 * 1024;
+// Lanes (of 64) that must want the inner-node block for a wave to run it without looking at the other blocks.
+uint32_t g_inner_min = 16;
 
 }  // namespace
 
@@ -66,6 +69,7 @@ struct rt_scene {
   int num_cus = 0;
   HostBvh host;
   size_t n_spheres = 0, n_materials = 0;
+  std::vector<uint8_t> material_type;
   void *d_nodes = nullptr, *d_spheres = nullptr, *d_aux = nullptr, *d_materials = nullptr;
   SceneDev dev{};
   rt_scene_info info{};
@@ -74,6 +78,38 @@ struct rt_scene {
 struct rt_host_bvh {
   HostBvh bvh;
 };
+
+static void dump_bvh(const HostBvh& b, double* boxes, int32_t* kind, uint64_t* skip_or_count, uint64_t* leaf_indices) {
+  for (size_t i = 0; i < b.nodes.size(); ++i) {
+    const HostNode& h = b.nodes[i];
+    if (boxes) {
+      std::memcpy(boxes + 6 * i, h.box.min, 24);
+      std::memcpy(boxes + 6 * i + 3, h.box.max, 24);
+    }
+    if (kind) kind[i] = h.kind;
+    if (skip_or_count) skip_or_count[i] = h.kind == 3 ? h.count : h.skip;
+  }
+  if (leaf_indices) std::memcpy(leaf_indices, b.leaf_indices.data(), b.leaf_indices.size() * 8);
+}
+
+static int make_camera_dev(const rt_config* cfg, CameraDev* cam, const char* who) {
+  if (!cfg) return fail(RT_ERR_INVALID, std::string(who) + ": cfg is null");
+  std::string why = config_check(*cfg);
+  if (!why.empty()) return fail(RT_ERR_INVALID, std::string(who) + ": " + why);
+  rt_camera c;
+  camera_derive(*cfg, &c);
+  std::memcpy(cam->center, c.center, 24);
+  std::memcpy(cam->pixel00, c.pixel00_loc, 24);
+  std::memcpy(cam->du, c.pixel_delta_u, 24);
+  std::memcpy(cam->dv, c.pixel_delta_v, 24);
+  std::memcpy(cam->disk_u, c.defocus_disk_u, 24);
+  std::memcpy(cam->disk_v, c.defocus_disk_v, 24);
+  cam->width = cfg->image_width;
+  cam->height = c.image_height;
+  cam->defocus = cfg->defocus_angle <= 0.0 ? 0u : 1u;  // src/camera.rs:127
+  cam->max_depth = (uint32_t)cfg->max_depth;
+  return RT_OK;
+}
 
 extern "C" {
 
@@ -95,7 +131,8 @@ int rt_scene_create(const rt_sphere* spheres, size_t n, const rt_material* mater
   if (!out) return fail(RT_ERR_INVALID, "rt_scene_create: out is null");
   *out = nullptr;
   if ((n && !spheres) || (nm && !materials)) return fail(RT_ERR_INVALID, "rt_scene_create: null array");
-  if (n >= (1ull << 30)) return fail(RT_ERR_LIMIT, "rt_scene_create: at most 2^30-1 spheres");
+  if (n >= kMaxSlots) return fail(RT_ERR_LIMIT, "rt_scene_create: at most 16777199 spheres");
+  if (nm >= (1ull << 30)) return fail(RT_ERR_LIMIT, "rt_scene_create: at most 2^30-1 materials");
   for (size_t i = 0; i < n; ++i) {
     const rt_sphere& s = spheres[i];
     for (int k = 0; k < 3; ++k)
@@ -133,49 +170,61 @@ int rt_scene_create(const rt_sphere* spheres, size_t n, const rt_material* mater
   sc->n_spheres = n;
   sc->n_materials = nm;
 
-  // Material table: 4 x 16 bytes each.
-  std::vector<double> mats(8 * nm, 0.0);
+  // Material table, 32 bytes each (layout documented at scatter() in rt_device.h); the type
+  // travels with the material index in each sphere slot's shading word.
+  std::vector<double> mats(4 * nm, 0.0);
+  sc->material_type.resize(nm);
   for (size_t i = 0; i < nm; ++i) {
     const rt_material& m = materials[i];
-    double* d = &mats[8 * i];
-    d[0] = m.albedo[0];
-    d[1] = m.albedo[1];
-    d[2] = m.albedo[2];
-    d[3] = m.param;
-    d[4] = 1.0 / m.param;  // Dielectric: ir.powi(-1), src/material.rs:52
-    double r0 = (1.0 - m.param) / (1.0 + m.param);  // Schlick r0, src/material.rs:47-48 (same value for ir and 1/ir up to rounding)
-    d[5] = r0 * r0;
-    uint64_t type = m.type;
-    std::memcpy(&d[6], &type, 8);
+    double* d = &mats[4 * i];
+    sc->material_type[i] = (uint8_t)m.type;
+    if (m.type == RT_DIELECTRIC) {
+      d[0] = m.param;
+      d[1] = 1.0 / m.param;                            // ir.powi(-1), src/material.rs:52
+      double r0 = (1.0 - m.param) / (1.0 + m.param);  // Schlick, src/material.rs:47-48
+      d[2] = r0 * r0;
+    } else {
+      d[0] = m.albedo[0];
+      d[1] = m.albedo[1];
+      d[2] = m.albedo[2];
+      d[3] = m.type == RT_METAL ? m.param : 0.0;
+    }
   }
+  for (auto& a : flat.aux) a.material |= (uint32_t)sc->material_type[a.material] << 30;
 
-  // LDS plan: the per-lane stacks come first; what is left holds the top of
-  // the tree and, if everything fits, the sphere records.  Two workgroups per
-  // CU when possible.
-  const uint32_t depth = sc->host.depth ? sc->host.depth : 1;
+  // LDS plan for one workgroup per CU: the per-lane stacks are mandatory; then, while they
+  // fit, the top of the tree, the sphere records, the slots' shading data and the materials.
+  const uint32_t depth = flat.depth ? flat.depth : 1;
   const size_t stack_bytes = (size_t)depth * kWorkgroup * 4;
-  size_t per_wg = kLdsPerCu / 2;
-  if (stack_bytes + 16 * 1024 > per_wg) per_wg = kLdsPerCu;
-  if (stack_bytes + 1024 > per_wg)
+  const size_t reserve = lds_fixed_bytes() + 64;
+  if (stack_bytes + reserve + 16 * 1024 > kLdsPerCu)
     return fail(RT_ERR_LIMIT, "rt_scene_create: BVH depth " + std::to_string(depth) + " needs more traversal stack than LDS holds");
-  const size_t room = per_wg - stack_bytes;
+  size_t room = kLdsPerCu - stack_bytes - reserve;
   const size_t node_bytes = flat.nodes.size() * sizeof(DevNode), sph_bytes = flat.spheres.size() * sizeof(DevSphere);
-  uint32_t n_nodes_lds, n_sph_lds = 0;
-  if (node_bytes + sph_bytes <= room) {
-    n_nodes_lds = (uint32_t)flat.nodes.size();
-    n_sph_lds = (uint32_t)flat.spheres.size();
-  } else {
-    n_nodes_lds = (uint32_t)std::min(flat.nodes.size(), room / sizeof(DevNode));
+  const size_t aux_bytes = flat.aux.size() * sizeof(DevSphereAux), mat_bytes = nm * 32;
+  uint32_t n_nodes_lds = (uint32_t)std::min(flat.nodes.size(), room / lds_node_bytes());
+  room -= n_nodes_lds * lds_node_bytes();
+  uint32_t n_sph_lds = 0, n_aux_lds = 0, n_mat_lds = 0;
+  if (n_nodes_lds == flat.nodes.size()) {
+    if (sph_bytes <= room) {
+      n_sph_lds = (uint32_t)n;
+      room -= sph_bytes;
+      if (aux_bytes <= room) {
+        n_aux_lds = (uint32_t)n;
+        room -= aux_bytes;
+        if (mat_bytes <= room) n_mat_lds = (uint32_t)nm;
+      }
+    }
   }
 
-  RT_HIP(hipMalloc(&sc->d_nodes, node_bytes ? node_bytes : 32));
+  RT_HIP(hipMalloc(&sc->d_nodes, node_bytes ? node_bytes : 64));
   RT_HIP(hipMalloc(&sc->d_spheres, sph_bytes ? sph_bytes : 32));
-  RT_HIP(hipMalloc(&sc->d_aux, flat.aux.size() ? flat.aux.size() * sizeof(DevSphereAux) : 16));
-  RT_HIP(hipMalloc(&sc->d_materials, nm ? nm * 64 : 64));
+  RT_HIP(hipMalloc(&sc->d_aux, aux_bytes ? aux_bytes : 16));
+  RT_HIP(hipMalloc(&sc->d_materials, mat_bytes ? mat_bytes : 32));
   if (node_bytes) RT_HIP(hipMemcpy(sc->d_nodes, flat.nodes.data(), node_bytes, hipMemcpyHostToDevice));
   if (sph_bytes) RT_HIP(hipMemcpy(sc->d_spheres, flat.spheres.data(), sph_bytes, hipMemcpyHostToDevice));
-  if (n) RT_HIP(hipMemcpy(sc->d_aux, flat.aux.data(), n * sizeof(DevSphereAux), hipMemcpyHostToDevice));
-  if (nm) RT_HIP(hipMemcpy(sc->d_materials, mats.data(), nm * 64, hipMemcpyHostToDevice));
+  if (aux_bytes) RT_HIP(hipMemcpy(sc->d_aux, flat.aux.data(), aux_bytes, hipMemcpyHostToDevice));
+  if (mat_bytes) RT_HIP(hipMemcpy(sc->d_materials, mats.data(), mat_bytes, hipMemcpyHostToDevice));
 
   sc->dev.nodes = static_cast<const float4*>(sc->d_nodes);
   sc->dev.spheres = static_cast<const double2*>(sc->d_spheres);
@@ -183,18 +232,25 @@ int rt_scene_create(const rt_sphere* spheres, size_t n, const rt_material* mater
   sc->dev.materials = static_cast<const double2*>(sc->d_materials);
   sc->dev.n_nodes = (uint32_t)flat.nodes.size();
   sc->dev.n_spheres = (uint32_t)n;
+  sc->dev.n_materials = (uint32_t)nm;
   sc->dev.n_nodes_lds = n_nodes_lds;
   sc->dev.n_spheres_lds = n_sph_lds;
+  sc->dev.n_aux_lds = n_aux_lds;
+  sc->dev.n_materials_lds = n_mat_lds;
   sc->dev.stack_cap = depth;
+  sc->dev.root = flat.root;
+  sc->dev.bound = flat.bound;
 
   sc->info.n_spheres = n;
-  sc->info.n_nodes = flat.nodes.size();
+  sc->info.n_nodes = sc->host.nodes.size();
+  sc->info.n_device_nodes = flat.nodes.size();
   sc->info.depth = sc->host.depth;
   sc->info.n_nodes_in_lds = n_nodes_lds;
-  sc->info.spheres_in_lds = n_sph_lds ? 1 : 0;
+  sc->info.spheres_in_lds = (n_sph_lds ? 1u : 0u) | (n_aux_lds ? 2u : 0u) | (n_mat_lds ? 4u : 0u);
   sc->info.device = (uint32_t)sc->device;
-  sc->info.device_bytes = node_bytes + sph_bytes + n * sizeof(DevSphereAux) + nm * 64;
+  sc->info.device_bytes = node_bytes + sph_bytes + aux_bytes + mat_bytes;
   sc->info.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  sc->info.lds_bytes = tree_lds_bytes(sc->dev);
 
   cleanup.s = nullptr;
   *out = sc;
@@ -216,19 +272,6 @@ int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
   if (!sc || !out) return fail(RT_ERR_INVALID, "rt_scene_get_info: null argument");
   *out = sc->info;
   return RT_OK;
-}
-
-static void dump_bvh(const HostBvh& b, double* boxes, int32_t* kind, uint64_t* skip_or_count, uint64_t* leaf_indices) {
-  for (size_t i = 0; i < b.nodes.size(); ++i) {
-    const HostNode& h = b.nodes[i];
-    if (boxes) {
-      std::memcpy(boxes + 6 * i, h.box.min, 24);
-      std::memcpy(boxes + 6 * i + 3, h.box.max, 24);
-    }
-    if (kind) kind[i] = h.kind;
-    if (skip_or_count) skip_or_count[i] = h.kind == 3 ? h.count : h.skip;
-  }
-  if (leaf_indices) std::memcpy(leaf_indices, b.leaf_indices.data(), b.leaf_indices.size() * 8);
 }
 
 int rt_scene_bvh_dump(const rt_scene* sc, double* boxes, int32_t* kind, uint64_t* skip_or_count, uint64_t* leaf_indices) {
@@ -280,7 +323,7 @@ int rt_trace_batch(const rt_scene* sc, const double* org, const double* dir, siz
   RT_HIP(hipMemcpy(d_org.p, org, n * 24, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(d_dir.p, dir, n * 24, hipMemcpyHostToDevice));
   RT_HIP(launch_trace_batch(sc->dev, d_org.as<double>(), d_dir.as<double>(), n, t_min, t_max, d_prim.as<int32_t>(), d_t.as<double>(),
-                            d_n.as<double>(), d_f.as<uint8_t>(), nullptr, sc->num_cus * 2, nullptr));
+                            d_n.as<double>(), d_f.as<uint8_t>(), nullptr, sc->num_cus, nullptr));
   RT_HIP(hipDeviceSynchronize());
   RT_HIP(hipMemcpy(prim, d_prim.p, n * 4, hipMemcpyDeviceToHost));
   RT_HIP(hipMemcpy(t, d_t.p, n * 8, hipMemcpyDeviceToHost));
@@ -295,8 +338,11 @@ int rt_scatter_batch(const rt_scene* sc, const uint32_t* material, const double*
   if (n == 0) return RT_OK;
   if (!material || !in_dir || !p || !normal || !front_face || !u || !scattered || !attenuation || !out_dir)
     return fail(RT_ERR_INVALID, "rt_scatter_batch: null buffer");
-  for (size_t i = 0; i < n; ++i)
+  std::vector<uint32_t> tagged(n);  // material index with its type in the top two bits, as the kernels carry it
+  for (size_t i = 0; i < n; ++i) {
     if (material[i] >= sc->n_materials) return fail(RT_ERR_INVALID, "rt_scatter_batch: material index out of range");
+    tagged[i] = material[i] | ((uint32_t)sc->material_type[material[i]] << 30);
+  }
   DeviceGuard g(sc->device);
   RT_HIP(g.status);
   DevBuf d_m, d_in, d_p, d_n, d_f, d_u, d_s, d_a, d_o;
@@ -309,7 +355,7 @@ int rt_scatter_batch(const rt_scene* sc, const uint32_t* material, const double*
   RT_HIP(d_s.alloc(n));
   RT_HIP(d_a.alloc(n * 24));
   RT_HIP(d_o.alloc(n * 24));
-  RT_HIP(hipMemcpy(d_m.p, material, n * 4, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(d_m.p, tagged.data(), n * 4, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(d_in.p, in_dir, n * 24, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(d_p.p, p, n * 24, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(d_n.p, normal, n * 24, hipMemcpyHostToDevice));
@@ -337,6 +383,7 @@ int rt_slab_batch(const double* boxes, const double* org, const double* dir, con
       if ((double)fh < hi) fh = std::nextafterf(fh, INFINITY);
       fb[8 * i + k] = fl;
       fb[8 * i + 4 + k] = fh;
+      fb[8 * i + 3] = std::fmax(fb[8 * i + 3], std::fmax(std::fabs(fl), std::fabs(fh)));  // the pad's bound on |coordinate|
     }
   DevBuf d_b, d_o, d_d, d_i, d_h;
   RT_HIP(d_b.alloc(n * 32));
@@ -351,25 +398,6 @@ int rt_slab_batch(const double* boxes, const double* org, const double* dir, con
   RT_HIP(launch_slab_batch(d_b.as<float>(), d_o.as<double>(), d_d.as<double>(), d_i.as<double>(), n, d_h.as<uint8_t>(), nullptr));
   RT_HIP(hipDeviceSynchronize());
   RT_HIP(hipMemcpy(hit, d_h.p, n, hipMemcpyDeviceToHost));
-  return RT_OK;
-}
-
-static int make_camera_dev(const rt_config* cfg, CameraDev* cam, const char* who) {
-  if (!cfg) return fail(RT_ERR_INVALID, std::string(who) + ": cfg is null");
-  std::string why = config_check(*cfg);
-  if (!why.empty()) return fail(RT_ERR_INVALID, std::string(who) + ": " + why);
-  rt_camera c;
-  camera_derive(*cfg, &c);
-  std::memcpy(cam->center, c.center, 24);
-  std::memcpy(cam->pixel00, c.pixel00_loc, 24);
-  std::memcpy(cam->du, c.pixel_delta_u, 24);
-  std::memcpy(cam->dv, c.pixel_delta_v, 24);
-  std::memcpy(cam->disk_u, c.defocus_disk_u, 24);
-  std::memcpy(cam->disk_v, c.defocus_disk_v, 24);
-  cam->width = cfg->image_width;
-  cam->height = c.image_height;
-  cam->defocus = cfg->defocus_angle <= 0.0 ? 0u : 1u;  // src/camera.rs:127
-  cam->max_depth = (uint32_t)cfg->max_depth;
   return RT_OK;
 }
 
@@ -434,10 +462,12 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
   if (n_items >= 0xffffffffull) return fail(RT_ERR_LIMIT, "rt_render: too many work items; render a smaller tile or sample range");
   P.n_items = (uint32_t)n_items;
   P.direct = n_chunks == 1 ? 1u : 0u;
+  P.inner_min = g_inner_min;
+  if (const char* env = std::getenv("RT_INNER_MIN")) P.inner_min = (uint32_t)std::atoi(env);
 
   DevBuf counters, partial;
-  RT_HIP(counters.alloc(3 * 8));
-  RT_HIP(hipMemsetAsync(counters.p, 0, 3 * 8, stream));
+  RT_HIP(counters.alloc(kRenderCounters * 8));
+  RT_HIP(hipMemsetAsync(counters.p, 0, kRenderCounters * 8, stream));
   P.counters = counters.as<unsigned long long>();
   if (P.direct) {
     P.out = rgb_sum_dev;
@@ -446,11 +476,10 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
     P.out = partial.as<double>();
   }
 
-  const size_t lds = tree_lds_bytes(sc->dev, kWorkgroup);
-  int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, kLdsPerCu / std::max<size_t>(lds, 1)));
-  int blocks = sc->num_cus * per_cu;
-  uint64_t waves_needed = (n_items + (kWorkgroup / 64) - 1) / (kWorkgroup / 64);
-  if ((uint64_t)blocks > waves_needed) blocks = (int)waves_needed;
+  // One persistent workgroup per CU (fewer if there is less work than that).
+  int blocks = sc->num_cus;
+  uint64_t wgs_needed = (n_items + (kWorkgroup / 64) - 1) / (kWorkgroup / 64);
+  if ((uint64_t)blocks > wgs_needed) blocks = (int)wgs_needed;
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   RT_HIP(hipEventCreate(&ev0));
@@ -464,7 +493,8 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
   } evg{ev0, ev1};
   RT_HIP(hipEventCreate(&ev1));
   RT_HIP(hipEventRecord(ev0, stream));
-  RT_HIP(launch_render(P, blocks, stream));
+  const bool profile = std::getenv("RT_PROFILE_BLOCKS") != nullptr;
+  RT_HIP(launch_render(P, blocks, profile, stream));
   uint32_t launches = 1;
   if (!P.direct) {
     RT_HIP(launch_reduce_chunks(partial.as<double>(), rgb_sum_dev, n_chunks, r.x0, r.y0, tw, th, P.cam.width, stream));
@@ -472,11 +502,10 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
   }
   RT_HIP(hipEventRecord(ev1, stream));
 
-  // The workspace is freed when this function returns, so the stream must
-  // have drained by then; callers that pass stats want that anyway.
+  // The workspace is freed when this function returns, so the stream must have drained by then.
   RT_HIP(hipStreamSynchronize(stream));
   if (stats) {
-    unsigned long long c[3];
+    unsigned long long c[kRenderCounters];
     RT_HIP(hipMemcpy(c, counters.p, sizeof(c), hipMemcpyDeviceToHost));
     float ms = 0.0f;
     RT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
@@ -484,6 +513,18 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
     stats->samples = c[2];
     stats->kernel_ms = ms;
     stats->launches = launches;
+    stats->node_steps = c[3];
+    stats->sphere_tests = c[4];
+    if (profile) {
+      const char* names[4] = {"camera", "inner", "leaf", "shade"};  // BLK_* order
+      for (int k = 0; k < 4; ++k)
+        std::fprintf(stderr, "rt profile: %-6s runs %llu mean active lanes %.1f cycles/run %.0f share of wave time %.3f\n", names[k],
+                     c[5 + 2 * k], c[5 + 2 * k] ? (double)c[6 + 2 * k] / (double)c[5 + 2 * k] : 0.0,
+                     c[5 + 2 * k] ? (double)c[13 + k] / (double)c[5 + 2 * k] : 0.0, c[17] ? (double)c[13 + k] / (double)c[17] : 0.0);
+      // Every wave is busy for (nearly) the whole launch, so stamped cycles / (waves x time) is the stamp clock's rate.
+      std::fprintf(stderr, "rt profile: kernel %.2f ms, %d waves, stamped cycles per wave-second %.3f GHz\n", ms, blocks * (int)(kWorkgroup / 64),
+                   (double)c[17] / (blocks * (double)(kWorkgroup / 64)) / (ms * 1e-3) / 1e9);
+    }
   }
   return RT_OK;
 }
@@ -507,6 +548,15 @@ int rt_render(const rt_scene* sc, const rt_config* cfg, uint64_t seed, uint32_t 
   RT_HIP(hipMemcpy(host.data(), img.p, n * 8, hipMemcpyDeviceToHost));
   for (size_t i = 0; i < n; ++i) rgb_sum[i] += host[i];
   return RT_OK;
+}
+
+int rt_debug_set(const char* name, double value) {
+  if (!name) return fail(RT_ERR_INVALID, "rt_debug_set: name is null");
+  if (std::strcmp(name, "inner_min") == 0) {
+    g_inner_min = (uint32_t)value;
+    return RT_OK;
+  }
+  return fail(RT_ERR_INVALID, std::string("rt_debug_set: unknown tunable ") + name);
 }
 
 int rt_quantise(const double* rgb_sum, size_t n_pixels, uint64_t spp, uint8_t* out) {

@@ -17,13 +17,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
                                               uint32_t out[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    // one 32x32->64 multiply per word pair (v_mad_u64_u32) instead of separate high and low products
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
     c0 = n0;
-    c1 = lo1;
+    c1 = (uint32_t)p1;
     c2 = n2;
-    c3 = lo0;
+    c3 = (uint32_t)p0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
@@ -57,6 +57,44 @@ __device__ __forceinline__ D3 operator*(D3 a, D3 b) { return {a.x * b.x, a.y * b
 __device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ D3 normalize(D3 a) { return rsqrt(dot(a, a)) * a; }
 
+// A double constant that is materialised where it is used (two scalar moves).
+// Without this the compiler hoists the polynomial coefficients below out of
+// the kernel's main loop into vector registers, runs out of registers, and
+// reloads them from scratch memory one by one on every evaluation.
+__device__ __forceinline__ double local_const(double c) {
+  asm volatile("" : "+s"(c));
+  return c;
+}
+
+// sin and cos of 2*pi*u for u in [0,1): the argument is reduced exactly to a
+// quarter turn q and a remainder |f| <= 1/8 of a turn, then the classic
+// minimax polynomials for sin and cos on [-pi/4, pi/4] are evaluated
+// (coefficients as in fdlibm's __kernel_sin/__kernel_cos; error about 1 ulp).
+__device__ __forceinline__ void sincos_2pi(double u, double& s, double& c) {
+  const double q = rint(4.0 * u);           // 0..4
+  const double f = fma(q, -0.25, u);        // exact, |f| <= 0.125
+  const double a = f * local_const(6.28318530717958647692528676655900577);
+  const double z = a * a;
+  double ps = local_const(1.58969099521155010221e-10);
+  ps = fma(ps, z, local_const(-2.50507602534068634195e-08));
+  ps = fma(ps, z, local_const(2.75573137070700676789e-06));
+  ps = fma(ps, z, local_const(-1.98412698298579493134e-04));
+  ps = fma(ps, z, local_const(8.33333333332248946124e-03));
+  ps = fma(ps, z, local_const(-1.66666666666666324348e-01));
+  const double sa = fma(a * z, ps, a);
+  double pc = local_const(-1.13596475577881948265e-11);
+  pc = fma(pc, z, local_const(2.08757232129817482790e-09));
+  pc = fma(pc, z, local_const(-2.75573143513906633035e-07));
+  pc = fma(pc, z, local_const(2.48015872894767294178e-05));
+  pc = fma(pc, z, local_const(-1.38888888888741095749e-03));
+  pc = fma(pc, z, local_const(4.16666666666666019037e-02));
+  const double ca = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int k = (int)q;  // rotate by k quarter turns
+  const double s1 = (k & 1) ? ca : sa, c1 = (k & 1) ? sa : ca;
+  s = (k & 2) ? -s1 : s1;
+  c = ((k + 1) & 2) ? -c1 : c1;
+}
+
 // Uniform point on the unit sphere from two uniforms: z = 1-2u0, phi = 2 pi u1.
 // Same distribution as normalising a point drawn uniformly in the unit ball
 // (vector::random_unit, src/vector.rs:16-27).
@@ -64,7 +102,7 @@ __device__ __forceinline__ D3 unit_from_uniforms(double u0, double u1) {
   double z = 1.0 - 2.0 * u0;
   double rxy = sqrt(fmax(0.0, 1.0 - z * z));
   double s, c;
-  sincospi(2.0 * u1, &s, &c);
+  sincos_2pi(u1, s, c);
   return d3(rxy * c, rxy * s, z);
 }
 // Uniform point in the unit disk: r = sqrt(u0), phi = 2 pi u1
@@ -72,28 +110,45 @@ __device__ __forceinline__ D3 unit_from_uniforms(double u0, double u1) {
 __device__ __forceinline__ void disk_from_uniforms(double u0, double u1, double& px, double& py) {
   double r = sqrt(u0);
   double s, c;
-  sincospi(2.0 * u1, &s, &c);
+  sincos_2pi(u1, s, c);
   px = r * c;
   py = r * s;
 }
 
 // --------------------------------------------------------------- camera ----
+typedef __attribute__((address_space(3))) double lds_double;
+// Where camera_ray reads the 18 camera constants from: the kernel argument
+// block, or a copy in LDS (read at the point of use, so they do not occupy
+// vector registers for the lifetime of the kernel).
+enum { CAM_CENTER = 0, CAM_PIXEL00 = 3, CAM_DU = 6, CAM_DV = 9, CAM_DISK_U = 12, CAM_DISK_V = 15, CAM_DOUBLES = 18 };
+struct CamArgs {
+  const CameraDev& c;
+  __device__ __forceinline__ D3 get(int k) const {
+    const double* p = k == CAM_CENTER ? c.center : k == CAM_PIXEL00 ? c.pixel00 : k == CAM_DU ? c.du : k == CAM_DV ? c.dv : k == CAM_DISK_U ? c.disk_u : c.disk_v;
+    return d3(p[0], p[1], p[2]);
+  }
+};
+struct CamLds {
+  lds_double* p;
+  __device__ __forceinline__ D3 get(int k) const { return d3(p[k], p[k + 1], p[k + 2]); }
+};
 // Camera::get_ray (src/camera.rs:114-136) for pixel (i,j), sample s.
-__device__ __forceinline__ void camera_ray(const CameraDev& cam, uint32_t k0, uint32_t k1, uint32_t i, uint32_t j, uint32_t s, D3& org,
-                                           D3& dir) {
-  const uint32_t pixel = j * cam.width + i;
-  const D3 du = d3(cam.du[0], cam.du[1], cam.du[2]), dv = d3(cam.dv[0], cam.dv[1], cam.dv[2]);
-  D3 pixel_center = d3(cam.pixel00[0], cam.pixel00[1], cam.pixel00[2]) + ((double)i * du) + ((double)j * dv);
+template <class Cam>
+__device__ __forceinline__ void camera_ray(const Cam& cam, uint32_t width, bool defocus, uint32_t k0, uint32_t k1, uint32_t i, uint32_t j,
+                                           uint32_t s, D3& org, D3& dir) {
+  const uint32_t pixel = j * width + i;
+  const D3 du = cam.get(CAM_DU), dv = cam.get(CAM_DV);
+  D3 pixel_center = cam.get(CAM_PIXEL00) + ((double)i * du) + ((double)j * dv);
   double u0, u1;
   philox_pair(k0, k1, pixel, s, 0, DOM_CAMERA, u0, u1);
   double px = -0.5 + u0, py = -0.5 + u1;
   D3 pixel_sample = pixel_center + ((px * du) + (py * dv));
-  org = d3(cam.center[0], cam.center[1], cam.center[2]);
-  if (cam.defocus) {
+  org = cam.get(CAM_CENTER);
+  if (defocus) {
     philox_pair(k0, k1, pixel, s, 1, DOM_CAMERA, u0, u1);
     double dx, dy;
     disk_from_uniforms(u0, u1, dx, dy);
-    org = org + dx * d3(cam.disk_u[0], cam.disk_u[1], cam.disk_u[2]) + dy * d3(cam.disk_v[0], cam.disk_v[1], cam.disk_v[2]);
+    org = org + dx * cam.get(CAM_DISK_U) + dy * cam.get(CAM_DISK_V);
   }
   dir = normalize(pixel_sample - org);
 }
@@ -101,37 +156,49 @@ __device__ __forceinline__ void camera_ray(const CameraDev& cam, uint32_t k0, ui
 // ------------------------------------------------------------- node test ----
 // The reference tests a node with f64 slabs (AABB::ray_intersection,
 // src/aabb.rs:69-82) and only the yes/no answer is used (src/bvh.rs:58).
-// Here the test runs in f32 on boxes rounded outwards.  Every rounding error
-// is covered by padding so that "miss" is returned only where the f64 test
-// also returns a miss; the closest hit found by traversal is therefore the
-// one the f64 traversal finds.
+// Here the test runs in f32 on boxes rounded outwards, and every rounding
+// error is covered by a pad, so that "miss" is returned only where the f64
+// test also returns a miss: traversal may enter a few more nodes than the
+// reference, never fewer, and finds the same closest hit.
 //
-// Per axis, with r = 1/d:  t = b*r - o*r, evaluated as fma(b, rf, c) where
-// c = -(o*r) -/+ e folds in an absolute pad e = 12 ulp_half * |o*r| (covers the
-// rounding of o, r and o*r), and the entry/exit distances get a relative pad
-// of 6 half-ulps.  An axis whose reciprocal is not a usable f32 number
-// (direction component ~ 0) constrains nothing, which is conservative.
-struct RayF32 {
-  float rf[3], cn[3], cf[3];
-};
+// Per axis, with r = 1/d, a plane b is crossed at t = b*r - o*r, evaluated
+// as fma(b, rf, c).  The constant c = -(o*r) -/+ e carries the pad
+//   e = 2^-24 * (6*B*|rf| + 12*|o*r|),  B = largest |plane coordinate| in the tree,
+// which bounds the rounding of o, r, o*r, of the product b*rf and of the fma
+// result (4*B*|r| + 7*|o*r| half-ulps are needed).  The pad is subtracted for
+// the plane the ray enters through and added for the one it leaves through;
+// which of lo/hi that is depends on the sign of r, so the two constants are
+// stored as (c_lo, c_hi) and entry/exit are min/max of the two products.
+// An axis whose reciprocal is not a usable f32 number (direction component
+// ~ 0) constrains nothing, which is conservative.
 #define RTA_U24 5.9604644775390625e-08f /* 2^-24 */
 
-__device__ __forceinline__ void ray_f32_axis(double o, double d, float& rf, float& cn, float& cf) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+struct RayBox {
+  float rx, ry, rz;  // reciprocal direction
+  f32x2 cx, cy, cz;  // (c_lo, c_hi) per axis
+};
+
+__device__ __forceinline__ void ray_box_axis(double o, double d, float bound, float& rf, f32x2& c2) {
   float df = (float)d;
   float r = __builtin_amdgcn_rcpf(df);
   float of = (float)o;
   float orf = of * r;
-  float e = fabsf(orf) * (12.0f * RTA_U24);
+  float e = RTA_U24 * (6.0f * bound * fabsf(r) + 12.0f * fabsf(orf));
   bool ok = fabsf(r) <= 1e18f;  // false for inf and NaN too
+  float cn = -orf - e, cf = -orf + e;
+  bool neg = r < 0.0f;
   rf = ok ? r : 0.0f;
-  cn = ok ? (-orf - e) : -__builtin_inff();
-  cf = ok ? (-orf + e) : __builtin_inff();
+  c2 = ok ? (neg ? f32x2{cf, cn} : f32x2{cn, cf}) : f32x2{-__builtin_inff(), __builtin_inff()};
 }
-__device__ __forceinline__ RayF32 ray_f32(D3 o, D3 d) {
-  RayF32 q;
-  ray_f32_axis(o.x, d.x, q.rf[0], q.cn[0], q.cf[0]);
-  ray_f32_axis(o.y, d.y, q.rf[1], q.cn[1], q.cf[1]);
-  ray_f32_axis(o.z, d.z, q.rf[2], q.cn[2], q.cf[2]);
+__device__ __forceinline__ RayBox ray_box(D3 o, D3 d, float bound) {
+  RayBox q;
+  ray_box_axis(o.x, d.x, bound, q.rx, q.cx);
+  ray_box_axis(o.y, d.y, bound, q.ry, q.cy);
+  ray_box_axis(o.z, d.z, bound, q.rz, q.cz);
   return q;
 }
 __device__ __forceinline__ float f32_below(double v) {  // largest f32 <= v
@@ -142,110 +209,181 @@ __device__ __forceinline__ float f32_above(double v) {  // smallest f32 >= v
   float f = (float)v;
   return ((double)f < v) ? nextafterf(f, __builtin_inff()) : f;
 }
-// negx/negy/negz: direction component < 0 (selects which plane is entered first).
-__device__ __forceinline__ bool node_test(const RayF32& q, bool negx, bool negy, bool negz, float4 n0, float4 n1, float tminf,
-                                          float tmaxf) {
-  float bnx = negx ? n1.x : n0.x, bfx = negx ? n0.x : n1.x;
-  float bny = negy ? n1.y : n0.y, bfy = negy ? n0.y : n1.y;
-  float bnz = negz ? n1.z : n0.z, bfz = negz ? n0.z : n1.z;
-  float tnx = fmaf(bnx, q.rf[0], q.cn[0]), tfx = fmaf(bfx, q.rf[0], q.cf[0]);
-  float tny = fmaf(bny, q.rf[1], q.cn[1]), tfy = fmaf(bfy, q.rf[1], q.cf[1]);
-  float tnz = fmaf(bnz, q.rf[2], q.cn[2]), tfz = fmaf(bfz, q.rf[2], q.cf[2]);
-  float tn = fmaxf(fmaxf(tnx, tny), tnz);
-  float tf = fminf(fminf(tfx, tfy), tfz);
-  tn = fmaf(-fabsf(tn), 6.0f * RTA_U24, tn);
-  tf = fmaf(fabsf(tf), 6.0f * RTA_U24, tf);
-  return !(tf < tn || tf < tminf || tmaxf < tn);
+// One box given as (lo, hi) pairs per axis: does the ray cross it within [tminf, tmaxf]?
+__device__ __forceinline__ bool box_test(const RayBox& q, f32x2 bx, f32x2 by, f32x2 bz, float tminf, float tmaxf) {
+  f32x2 tx = __builtin_elementwise_fma(bx, f32x2{q.rx, q.rx}, q.cx);
+  f32x2 ty = __builtin_elementwise_fma(by, f32x2{q.ry, q.ry}, q.cy);
+  f32x2 tz = __builtin_elementwise_fma(bz, f32x2{q.rz, q.rz}, q.cz);
+  float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tminf));
+  float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tmaxf));
+  return tn <= tf;
 }
 
 // ------------------------------------------------------------- traversal ----
+// Device tree: inner nodes only, 64 bytes each, holding the boxes of both
+// children (so a child that the ray misses is never fetched):
+//   q0 = (lo0.x, hi0.x, lo1.x, hi1.x)   q1 = the same for y   q2 = for z
+//   q3 = (ref0, ref1, split axis, 0) as integers
+// A ref names an inner node (bit 31 clear) or a leaf: bit 31 set, bits 30..24
+// the sphere count (1..127), bits 23..0 the first sphere slot.
+constexpr uint32_t kRefLeaf = 0x80000000u;
+constexpr uint32_t kRefDone = 0xffffffffu;  // traversal finished / empty tree
+// Two more values the render kernel keeps in the same register to say what a lane wants next.
+constexpr uint32_t kRefCamera = 0xfffffffeu;  // start the next sample
+constexpr uint32_t kRefIdle = 0xfffffffdu;    // nothing left to do; every leaf ref is below this value
+constexpr uint32_t kLdsNodeQuads = 5;         // LDS stride of a node in 16-byte words (80 B: spreads nodes over banks)
+
+typedef __attribute__((address_space(3))) f32x4 lds_float4;
+typedef __attribute__((address_space(3))) f64x2 lds_double2;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
 struct TreeView {
   const float4* gnodes;
-  const float4* lnodes;  // LDS copy of nodes [0, n_lds)
+  lds_float4* lnodes;  // LDS copy of nodes [0, n_lds), kLdsNodeQuads apart
   const double2* gsph;
-  const double2* lsph;  // LDS copy of the sphere slots, or nullptr
-  uint32_t n_nodes, n_lds, n_sph_lds;
+  lds_double2* lsph;  // LDS copy of sphere slots [0, n_sph_lds)
+  const double2* gaux;
+  lds_double2* laux;  // LDS copy of the slots' shading data [0, n_aux_lds)
+  const double2* gmat;
+  lds_double2* lmat;  // LDS copy of materials [0, n_mat_lds)
+  uint32_t n_lds, n_sph_lds, n_aux_lds, n_mat_lds;
+  uint32_t root;
+  float bound;
 };
 
-__device__ __forceinline__ void fetch_node(const TreeView& tv, uint32_t i, float4& n0, float4& n1) {
-  if (i < tv.n_lds) {
-    n0 = tv.lnodes[2 * i];
-    n1 = tv.lnodes[2 * i + 1];
+// kAllLds: the whole tree and all spheres are in LDS, so no global path is compiled in.
+template <bool kAllLds>
+__device__ __forceinline__ void fetch_node(const TreeView& tv, uint32_t i, f32x4& q0, f32x4& q1, f32x4& q2, f32x4& q3) {
+  if (kAllLds || i < tv.n_lds) {
+    lds_float4* p = (lds_float4*)((__attribute__((address_space(3))) char*)tv.lnodes + __umul24(i, kLdsNodeQuads * 16u));  // full-rate 24-bit multiply
+    q0 = p[0];
+    q1 = p[1];
+    q2 = p[2];
+    q3 = p[3];
   } else {
-    n0 = tv.gnodes[2 * i];
-    n1 = tv.gnodes[2 * i + 1];
+    const f32x4* p = reinterpret_cast<const f32x4*>(tv.gnodes) + 4 * (size_t)i;
+    q0 = p[0];
+    q1 = p[1];
+    q2 = p[2];
+    q3 = p[3];
   }
 }
-__device__ __forceinline__ void fetch_sphere(const TreeView& tv, uint32_t slot, double2& s0, double2& s1) {
-  if (slot < tv.n_sph_lds) {
+static_assert(kLdsNodeQuads == 5, "fetch_node computes 5*i");
+
+template <bool kAllLds>
+__device__ __forceinline__ void fetch_sphere(const TreeView& tv, uint32_t slot, f64x2& s0, f64x2& s1) {
+  if (kAllLds || slot < tv.n_sph_lds) {
     s0 = tv.lsph[2 * slot];
     s1 = tv.lsph[2 * slot + 1];
   } else {
-    s0 = tv.gsph[2 * slot];
-    s1 = tv.gsph[2 * slot + 1];
+    const f64x2* p = reinterpret_cast<const f64x2*>(tv.gsph) + 2 * (size_t)slot;
+    s0 = p[0];
+    s1 = p[1];
   }
 }
 
-// BVH::hit (src/bvh.rs:50-84): closest hit in (t_min, t_max), the nearer child
-// first (by the sign of the direction on the split axis), spheres of a leaf in
-// stored order, a later hit must be strictly closer (Interval::surrounds,
-// src/ray.rs:35-37).  The reference pushes both children and pops the nearer;
-// here the nearer child is entered directly and the other is pushed, which
-// visits nodes in the same order.  `stack` is this lane's column of the LDS
-// stack, entries `stride` words apart; its capacity is the depth of the tree.
-// Returns the slot of the hit sphere (or -1) and its distance in t_best.
-__device__ __forceinline__ int traverse(const TreeView& tv, uint32_t* stack, uint32_t stride, D3 o, D3 d, double t_min, double t_max,
-                                        double& t_best, uint32_t& n_visits) {
-  int best = -1;
-  t_best = t_max;
-  if (tv.n_nodes == 0) return best;
-  const RayF32 q = ray_f32(o, d);
-  const bool negx = d.x < 0.0, negy = d.y < 0.0, negz = d.z < 0.0;
-  const float tminf = f32_below(t_min);
-  float tmaxf = (t_max < 3.0e38) ? f32_above(t_max) : __builtin_inff();
-  // Sphere::hit (src/sphere.rs:29-48) terms that depend on the ray only.
-  const double a = dot(d, d);
-  const double inv_a = 1.0 / a;
-  uint32_t cur = 0, sp = 0;
-  for (;;) {
-    float4 n0, n1;
-    fetch_node(tv, cur, n0, n1);
-    ++n_visits;
-    if (node_test(q, negx, negy, negz, n0, n1, tminf, tmaxf)) {
-      const uint32_t na = __float_as_uint(n0.w), nb = __float_as_uint(n1.w);
-      if (!(nb & 0x80000000u)) {
-        const bool neg = nb == 0 ? negx : nb == 1 ? negy : negz;
-        // direction < 0 on the split axis: right child first (src/bvh.rs:64-68)
-        stack[sp * stride] = na + (neg ? 0u : 1u);
-        ++sp;
-        cur = na + (neg ? 1u : 0u);
-        continue;
-      }
-      const uint32_t count = nb & 0x7fffffffu;
-      for (uint32_t k = 0; k < count; ++k) {
-        double2 s0, s1;
-        fetch_sphere(tv, na + k, s0, s1);
-        D3 oc = d3(o.x - s0.x, o.y - s0.y, o.z - s1.x);
-        double half_b = dot(oc, d);
-        double c = dot(oc, oc) - s1.y * s1.y;
-        double disc = half_b * half_b - a * c;
-        if (disc >= 0.0) {
-          double sq = sqrt(disc);
-          double t = (-half_b - sq) * inv_a;
-          if (!(t_min < t && t < t_best)) t = (-half_b + sq) * inv_a;
-          if (t_min < t && t < t_best) {
-            t_best = t;
-            best = (int)(na + k);
-            tmaxf = f32_above(t);
-          }
-        }
+// State of one lane's closest-hit query, BVH::hit (src/bvh.rs:50-84).
+//
+// Order of visits is the reference's: at a split the child on the side the
+// ray comes from goes first (right child first when the direction is negative
+// on the split axis, src/bvh.rs:64-68), spheres of a leaf in stored order, and
+// a later hit replaces the current one only if strictly closer
+// (Interval::surrounds, src/ray.rs:35-37).  The reference pushes both children
+// and tests each node's own box when it is popped; here both child boxes are
+// tested at the parent, the first child that is hit becomes current and the
+// other is pushed.  `stack` is this lane's column of the LDS stack, entries
+// `stride` words apart; the tree is never deeper than its capacity.
+struct Trav {
+  D3 o, d;
+  RayBox q;
+  double t_best;
+  float tmaxf;
+  uint32_t sgn;  // bit a set: direction negative on axis a
+  uint32_t cur, sp;
+  int best;
+};
+
+__device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D3 d, double t_max) {
+  tr.o = o;
+  tr.d = d;
+  tr.q = ray_box(o, d, tv.bound);
+  tr.t_best = t_max;
+  tr.tmaxf = (t_max < 3.0e38) ? f32_above(t_max) : __builtin_inff();
+  tr.sgn = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
+  tr.cur = tv.root;
+  tr.sp = 0;
+  tr.best = -1;
+}
+
+__device__ __forceinline__ void trav_pop(Trav& tr, lds_u32* stack, uint32_t stride) {
+  if (tr.sp == 0) {
+    tr.cur = kRefDone;
+  } else {
+    --tr.sp;
+    tr.cur = stack[tr.sp * stride];
+  }
+}
+
+// One inner node: test both children, descend into the first one hit.
+template <bool kAllLds>
+__device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, lds_u32* stack, uint32_t stride, float tminf) {
+  f32x4 q0, q1, q2, q3;
+  fetch_node<kAllLds>(tv, tr.cur, q0, q1, q2, q3);
+  const bool h0 = box_test(tr.q, f32x2{q0.x, q0.y}, f32x2{q1.x, q1.y}, f32x2{q2.x, q2.y}, tminf, tr.tmaxf);
+  const bool h1 = box_test(tr.q, f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, tminf, tr.tmaxf);
+  const uint32_t ref0 = __float_as_uint(q3.x), ref1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
+  const bool swap = ((tr.sgn >> axis) & 1u) != 0u;
+  if (h0 && h1) {
+    stack[tr.sp * stride] = swap ? ref0 : ref1;
+    ++tr.sp;
+    tr.cur = swap ? ref1 : ref0;
+  } else if (h0 || h1) {
+    tr.cur = h0 ? ref0 : ref1;
+  } else {
+    trav_pop(tr, stack, stride);
+  }
+}
+
+// One leaf: Sphere::hit (src/sphere.rs:29-48) for each of its spheres.  The
+// direction has unit length, so the reference's a = |d|^2 is taken as 1.
+template <bool kAllLds>
+__device__ __forceinline__ void trav_leaf_step(Trav& tr, const TreeView& tv, lds_u32* stack, uint32_t stride, double t_min,
+                                               uint32_t& n_tests) {
+  const uint32_t first = tr.cur & 0x00ffffffu, count = (tr.cur >> 24) & 0x7fu;
+  for (uint32_t k = 0; k < count; ++k) {
+    f64x2 s0, s1;
+    fetch_sphere<kAllLds>(tv, first + k, s0, s1);
+    ++n_tests;
+    D3 oc = d3(tr.o.x - s0.x, tr.o.y - s0.y, tr.o.z - s1.x);
+    double half_b = dot(oc, tr.d);
+    double c = dot(oc, oc) - s1.y * s1.y;
+    double disc = half_b * half_b - c;
+    if (disc >= 0.0) {
+      double sq = sqrt(disc);
+      double t = -half_b - sq;
+      if (!(t_min < t && t < tr.t_best)) t = -half_b + sq;
+      if (t_min < t && t < tr.t_best) {
+        tr.t_best = t;
+        tr.best = (int)(first + k);
+        tr.tmaxf = f32_above(t);
       }
     }
-    if (sp == 0) break;
-    --sp;
-    cur = stack[sp * stride];
   }
-  return best;
+  trav_pop(tr, stack, stride);
+}
+
+// Runs the query to completion (all lanes of the wave together).
+template <bool kAllLds>
+__device__ __forceinline__ void trav_run(Trav& tr, const TreeView& tv, lds_u32* stack, uint32_t stride, double t_min, uint32_t& n_steps,
+                                         uint32_t& n_tests) {
+  const float tminf = f32_below(t_min);
+  while (tr.cur != kRefDone) {
+    while (!(tr.cur & kRefLeaf)) {
+      trav_inner_step<kAllLds>(tr, tv, stack, stride, tminf);
+      ++n_steps;
+    }
+    if (tr.cur != kRefDone) trav_leaf_step<kAllLds>(tr, tv, stack, stride, t_min, n_tests);
+  }
 }
 
 // ---------------------------------------------------------------- shading ----
@@ -255,10 +393,15 @@ struct Hit {
   uint32_t material, prim;
 };
 // HitRecord::new (src/hit.rs:18-27) for the sphere in `slot` at distance t.
-__device__ __forceinline__ Hit make_hit(const TreeView& tv, const double2* aux, int slot, D3 o, D3 d, double t) {
-  double2 s0, s1;
-  fetch_sphere(tv, (uint32_t)slot, s0, s1);
-  double2 ax = aux[slot];
+// h.material carries the material index (low 30 bits) and type (top 2 bits).
+template <bool kAllLds>
+__device__ __forceinline__ Hit make_hit(const TreeView& tv, int slot, D3 o, D3 d, double t) {
+  f64x2 s0, s1, ax;
+  fetch_sphere<kAllLds>(tv, (uint32_t)slot, s0, s1);
+  if (kAllLds || (uint32_t)slot < tv.n_aux_lds)
+    ax = tv.laux[slot];
+  else
+    ax = reinterpret_cast<const f64x2*>(tv.gaux)[slot];
   Hit h;
   h.p = d3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
   D3 n = ax.x * d3(h.p.x - s0.x, h.p.y - s0.y, h.p.z - s1.x);
@@ -271,21 +414,32 @@ __device__ __forceinline__ Hit make_hit(const TreeView& tv, const double2* aux, 
 }
 
 // Material::scatter (src/material.rs:21-65).  `d` is the unit direction of the
-// incoming ray.  Returns false where the reference returns None.
-__device__ __forceinline__ bool scatter(const double2* materials, uint32_t mat, D3 d, const Hit& h, double u0, double u1, D3& attenuation,
+// incoming ray, `mat` the material index with its type in the top 2 bits.
+// Material record (32 bytes): Lambertian/Metal (albedo.x, albedo.y)(albedo.z, fuzz);
+// Dielectric (ir, 1/ir)(r0, -) with r0 = ((1-ir)/(1+ir))^2, which is the same
+// number for ir and 1/ir.  Returns false where the reference returns None.
+template <bool kAllLds>
+__device__ __forceinline__ bool scatter(const TreeView& tv, uint32_t mat, D3 d, const Hit& h, double u0, double u1, D3& attenuation,
                                         D3& out_dir) {
-  const double2 m0 = materials[4 * mat], m1 = materials[4 * mat + 1], m2 = materials[4 * mat + 2], m3 = materials[4 * mat + 3];
-  const uint32_t type = (uint32_t)__double_as_longlong(m3.x);
-  attenuation = d3(m0.x, m0.y, m1.x);
+  const uint32_t type = mat >> 30, index = mat & 0x3fffffffu;
+  f64x2 m0, m1;
+  if (kAllLds || index < tv.n_mat_lds) {
+    m0 = tv.lmat[2 * index];
+    m1 = tv.lmat[2 * index + 1];
+  } else {
+    const f64x2* p = reinterpret_cast<const f64x2*>(tv.gmat) + 2 * (size_t)index;
+    m0 = p[0];
+    m1 = p[1];
+  }
   D3 dir;
   if (type == 2u) {  // Dielectric
     attenuation = d3(1.0, 1.0, 1.0);
-    double ratio = h.front ? m2.x : m1.y;  // ir^-1 entering, ir leaving
+    double ratio = h.front ? m0.y : m0.x;  // ir^-1 entering, ir leaving (src/material.rs:52)
     double cos_theta = fmin(-dot(d, h.normal), 1.0);
     double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
     bool cannot_refract = ratio * sin_theta > 1.0;
     double x = 1.0 - cos_theta, x2 = x * x;
-    double reflectance = m2.y + (1.0 - m2.y) * (x2 * x2 * x);  // Schlick, src/material.rs:45-50
+    double reflectance = m1.x + (1.0 - m1.x) * (x2 * x2 * x);  // Schlick, src/material.rs:45-50
     if (cannot_refract || reflectance > u0) {
       dir = d - (2.0 * dot(d, h.normal)) * h.normal;  // vector::reflect, src/vector.rs:56-58
     } else {  // vector::refract, src/vector.rs:60-65
@@ -294,6 +448,7 @@ __device__ __forceinline__ bool scatter(const double2* materials, uint32_t mat, 
       dir = perp + par * h.normal;
     }
   } else {
+    attenuation = d3(m0.x, m0.y, m1.x);
     D3 unit = unit_from_uniforms(u0, u1);
     if (type == 0u) {  // Lambertian
       dir = h.normal + unit;

@@ -5,44 +5,76 @@
 
 namespace rta {
 
-// LDS image of a workgroup: [top-of-tree nodes][sphere slots][per-lane stacks].
-__device__ __forceinline__ TreeView stage_tree(const SceneDev& sc, float4* smem, uint32_t*& stack_base, uint32_t wg) {
-  float4* lnodes = smem;
-  double2* lsph = reinterpret_cast<double2*>(smem + 2 * sc.n_nodes_lds);
-  stack_base = reinterpret_cast<uint32_t*>(lsph + 2 * sc.n_spheres_lds);
-  for (uint32_t i = threadIdx.x; i < 2 * sc.n_nodes_lds; i += wg) lnodes[i] = sc.nodes[i];
-  for (uint32_t i = threadIdx.x; i < 2 * sc.n_spheres_lds; i += wg) lsph[i] = sc.spheres[i];
-  __syncthreads();
+// LDS image of a workgroup:
+//   [camera constants][top-of-tree nodes][sphere slots][slot shading data][materials][per-lane stacks]
+struct LdsImage {
   TreeView tv;
-  tv.gnodes = sc.nodes;
-  tv.lnodes = lnodes;
-  tv.gsph = sc.spheres;
-  tv.lsph = lsph;
-  tv.n_nodes = sc.n_nodes;
-  tv.n_lds = sc.n_nodes_lds;
-  tv.n_sph_lds = sc.n_spheres_lds;
-  return tv;
+  CamLds cam;
+  lds_u32* stack_base;
+};
+
+__device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const CameraDev* cam, float4* smem, uint32_t wg) {
+  lds_double* lcam = (lds_double*)smem;
+  lds_float4* lnodes = (lds_float4*)(lcam + CAM_DOUBLES);
+  lds_double2* lsph = (lds_double2*)(lnodes + kLdsNodeQuads * sc.n_nodes_lds);
+  lds_double2* laux = lsph + 2 * sc.n_spheres_lds;
+  lds_double2* lmat = laux + sc.n_aux_lds;
+  lds_u32* stack_base = (lds_u32*)(lmat + 2 * sc.n_materials_lds);
+  const f32x4* gn = reinterpret_cast<const f32x4*>(sc.nodes);
+  const f64x2* gs = reinterpret_cast<const f64x2*>(sc.spheres);
+  const f64x2* ga = reinterpret_cast<const f64x2*>(sc.aux);
+  const f64x2* gm = reinterpret_cast<const f64x2*>(sc.materials);
+  if (cam && threadIdx.x < CAM_DOUBLES) {
+    const uint32_t k = threadIdx.x;
+    const double* src = k < 3 ? cam->center : k < 6 ? cam->pixel00 : k < 9 ? cam->du : k < 12 ? cam->dv : k < 15 ? cam->disk_u : cam->disk_v;
+    lcam[k] = src[k % 3];
+  }
+  for (uint32_t i = threadIdx.x; i < 4 * sc.n_nodes_lds; i += wg) lnodes[(i >> 2) * kLdsNodeQuads + (i & 3u)] = gn[i];
+  for (uint32_t i = threadIdx.x; i < 2 * sc.n_spheres_lds; i += wg) lsph[i] = gs[i];
+  for (uint32_t i = threadIdx.x; i < sc.n_aux_lds; i += wg) laux[i] = ga[i];
+  for (uint32_t i = threadIdx.x; i < 2 * sc.n_materials_lds; i += wg) lmat[i] = gm[i];
+  __syncthreads();
+  LdsImage im;
+  im.tv.gnodes = sc.nodes;
+  im.tv.lnodes = lnodes;
+  im.tv.gsph = sc.spheres;
+  im.tv.lsph = lsph;
+  im.tv.gaux = sc.aux;
+  im.tv.laux = laux;
+  im.tv.gmat = sc.materials;
+  im.tv.lmat = lmat;
+  im.tv.n_lds = sc.n_nodes_lds;
+  im.tv.n_sph_lds = sc.n_spheres_lds;
+  im.tv.n_aux_lds = sc.n_aux_lds;
+  im.tv.n_mat_lds = sc.n_materials_lds;
+  im.tv.root = sc.root;
+  im.tv.bound = sc.bound;
+  im.cam.p = lcam;
+  im.stack_base = stack_base;
+  return im;
 }
 
 // ------------------------------------------------------------ trace batch ----
+template <bool kAllLds>
 __global__ __launch_bounds__(kWorkgroup) void trace_batch_kernel(SceneDev sc, const double* __restrict__ org, const double* __restrict__ dir,
                                                                  size_t n, double t_min, double t_max, int32_t* __restrict__ prim,
                                                                  double* __restrict__ t_out, double* __restrict__ normal,
-                                                                 uint8_t* __restrict__ front, uint32_t* __restrict__ visits) {
+                                                                 uint8_t* __restrict__ front, uint32_t* __restrict__ counts) {
   extern __shared__ float4 smem[];
-  uint32_t* stack_base;
-  TreeView tv = stage_tree(sc, smem, stack_base, kWorkgroup);
-  uint32_t* stack = stack_base + threadIdx.x;
+  const LdsImage im = stage_scene(sc, nullptr, smem, kWorkgroup);
+  const TreeView& tv = im.tv;
+  lds_u32* stack = im.stack_base + threadIdx.x;
   for (size_t i = (size_t)blockIdx.x * kWorkgroup + threadIdx.x; i < n; i += (size_t)gridDim.x * kWorkgroup) {
     D3 o = d3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
     D3 d = normalize(d3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));  // Ray::new, src/ray.rs:16-23
-    double t;
-    uint32_t nv = 0;
-    int slot = traverse(tv, stack, kWorkgroup, o, d, t_min, t_max, t, nv);
-    if (slot >= 0) {
-      Hit h = make_hit(tv, sc.aux, slot, o, d, t);
+    Trav tr;
+    trav_begin(tr, tv, o, d, t_max);
+    uint32_t n_steps = 0, n_tests = 0;
+    trav_run<kAllLds>(tr, tv, stack, kWorkgroup, t_min, n_steps, n_tests);
+    if (tr.best >= 0) {
+      Hit h = make_hit<kAllLds>(tv, tr.best, o, d, tr.t_best);
       prim[i] = (int32_t)h.prim;
-      t_out[i] = t;
+      t_out[i] = tr.t_best;
       normal[3 * i] = h.normal.x;
       normal[3 * i + 1] = h.normal.y;
       normal[3 * i + 2] = h.normal.z;
@@ -53,7 +85,10 @@ __global__ __launch_bounds__(kWorkgroup) void trace_batch_kernel(SceneDev sc, co
       normal[3 * i] = normal[3 * i + 1] = normal[3 * i + 2] = 0.0;
       front[i] = 0;
     }
-    if (visits) visits[i] = nv;
+    if (counts) {
+      counts[2 * i] = n_steps;
+      counts[2 * i + 1] = n_tests;
+    }
   }
 }
 
@@ -65,6 +100,8 @@ __global__ __launch_bounds__(256) void scatter_batch_kernel(const double2* __res
                                                             double* __restrict__ attenuation, double* __restrict__ out_dir) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  TreeView tv{};  // only the global material table is used
+  tv.gmat = materials;
   D3 d = normalize(d3(in_dir[3 * i], in_dir[3 * i + 1], in_dir[3 * i + 2]));
   Hit h;
   h.p = d3(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
@@ -73,7 +110,7 @@ __global__ __launch_bounds__(256) void scatter_batch_kernel(const double2* __res
   h.material = mat[i];
   h.prim = 0;
   D3 att, od;
-  bool ok = scatter(materials, h.material, d, h, u[2 * i], u[2 * i + 1], att, od);
+  bool ok = scatter<false>(tv, h.material, d, h, u[2 * i], u[2 * i + 1], att, od);
   scattered[i] = ok ? 1 : 0;
   if (!ok) att = od = d3(0.0, 0.0, 0.0);
   attenuation[3 * i] = att.x;
@@ -85,7 +122,7 @@ __global__ __launch_bounds__(256) void scatter_batch_kernel(const double2* __res
 }
 
 // ------------------------------------------------------------- slab batch ----
-// boxes: n x 2 float4 (already rounded outwards by the host).
+// boxes: n x 2 float4 = (lo.xyz, bound) (hi.xyz, -), already rounded outwards by the host.
 __global__ __launch_bounds__(256) void slab_batch_kernel(const float4* __restrict__ boxes, const double* __restrict__ org,
                                                          const double* __restrict__ dir, const double* __restrict__ interval, size_t n,
                                                          uint8_t* __restrict__ hit) {
@@ -93,11 +130,12 @@ __global__ __launch_bounds__(256) void slab_batch_kernel(const float4* __restric
   if (i >= n) return;
   D3 o = d3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
   D3 d = normalize(d3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
-  RayF32 q = ray_f32(o, d);
+  const float4 lo = boxes[2 * i], hi = boxes[2 * i + 1];
+  RayBox q = ray_box(o, d, lo.w);
   double t_min = interval[2 * i], t_max = interval[2 * i + 1];
   float tminf = f32_below(t_min);
   float tmaxf = (t_max < 3.0e38) ? f32_above(t_max) : __builtin_inff();
-  hit[i] = node_test(q, d.x < 0.0, d.y < 0.0, d.z < 0.0, boxes[2 * i], boxes[2 * i + 1], tminf, tmaxf) ? 1 : 0;
+  hit[i] = box_test(q, f32x2{lo.x, hi.x}, f32x2{lo.y, hi.y}, f32x2{lo.z, hi.z}, tminf, tmaxf) ? 1 : 0;
 }
 
 // ----------------------------------------------------------- primary rays ----
@@ -106,7 +144,7 @@ __global__ __launch_bounds__(256) void primary_rays_kernel(CameraDev cam, uint32
   size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= n) return;
   D3 o, d;
-  camera_ray(cam, k0, k1, ijs[3 * k], ijs[3 * k + 1], ijs[3 * k + 2], o, d);
+  camera_ray(CamArgs{cam}, cam.width, cam.defocus != 0, k0, k1, ijs[3 * k], ijs[3 * k + 1], ijs[3 * k + 2], o, d);
   org[3 * k] = o.x;
   org[3 * k + 1] = o.y;
   org[3 * k + 2] = o.z;
@@ -119,19 +157,51 @@ __global__ __launch_bounds__(256) void primary_rays_kernel(CameraDev cam, uint32
 // The per-pixel closure of Camera::render (src/camera.rs:144-153) with
 // Camera::ray_colour (src/camera.rs:98-112) unrolled into a loop.
 //
-// Persistent workgroups: each stages the tree in LDS once, then its waves
-// pull work items (an 8x8 pixel tile x a chunk of the sample range) from a
-// global counter.  A lane owns one pixel of the tile; it starts its next
-// sample as soon as its current path ends, so lanes of a wave do not wait for
-// each other between samples.  Each lane adds its samples in index order, so
-// the result does not depend on how items are scheduled.
-__global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {
+// Persistent workgroups, one per CU: each stages the scene in LDS once, then
+// its waves pull work items (an 8x8 pixel tile x a chunk of the sample range)
+// from a global counter.  A lane owns one pixel of the tile and walks through
+// its samples in index order, so the sums do not depend on scheduling.
+//
+// Every lane is a small state machine that wants exactly one of four code
+// blocks next: CAMERA (start the next sample), INNER (one inner BVH node:
+// test both child boxes), LEAF (the spheres of one leaf) or SHADE (closest hit
+// known: sky or scatter, then the next ray or the end of the path).  Path and
+// traversal lengths differ from lane to lane, so instead of running every
+// lane's traversal to completion before shading, the wave counts with ballots
+// how many lanes want each block and runs one block per iteration: INNER
+// while at least `inner_min` lanes want it, otherwise the block most lanes are
+// waiting for.  Which block runs when never changes a lane's own sequence of
+// operations, so results do not depend on the policy.
+enum : uint32_t { PH_CAMERA = 0, PH_TRAV = 1, PH_DONE = 2 };
+enum { BLK_CAMERA = 0, BLK_INNER = 1, BLK_LEAF = 2, BLK_SHADE = 3 };
+
+// kProf: also count, per code block, how often it ran and with how many active lanes.
+#define RTA_PROF(k)                                              \
+  if (kProf) {                                                    \
+    const unsigned long long m_ = __ballot(1);                    \
+    if (lane == (uint32_t)__ffsll((long long)m_) - 1u) {          \
+      prof_runs[k] += 1;                                          \
+      prof_lanes[k] += (uint32_t)__popcll(m_);                    \
+    }                                                             \
+  }
+// Shader-clock stamps around a block (profiling variant only).
+#define RTA_T0()              \
+  unsigned long long t0_ = 0; \
+  if (kProf) t0_ = __builtin_amdgcn_s_memtime();
+#define RTA_T1(k) \
+  if (kProf) prof_cycles[k] += __builtin_amdgcn_s_memtime() - t0_;
+
+template <bool kAllLds, bool kProf>
+__global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  // 16 waves per CU: at most 128 VGPRs
   extern __shared__ float4 smem[];
-  uint32_t* stack_base;
-  const TreeView tv = stage_tree(P.sc, smem, stack_base, kWorkgroup);
-  uint32_t* stack = stack_base + threadIdx.x;
+  const LdsImage im = stage_scene(P.sc, &P.cam, smem, kWorkgroup);
+  const TreeView& tv = im.tv;
+  // The lane's stack column is recomputed where it is used (one add), not kept in a register.
+#define RTA_STACK (im.stack_base + threadIdx.x)
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t tile_w = P.x1 - P.x0;
+  const double t_min = 1e-3;  // src/camera.rs:102
+  const float tminf = f32_below(t_min);
 
   for (;;) {
     uint32_t item = 0;
@@ -140,57 +210,112 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {
     if (item >= P.n_items) break;
     const uint32_t tile = item / P.n_chunks, chunk = item - tile * P.n_chunks;
     const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-    const uint32_t i = P.x0 + tx * 8u + (lane & 7u), j = P.y0 + ty * 8u + (lane >> 3);
-    const bool valid = i < P.x1 && j < P.y1;
+    const uint32_t i0 = P.x0 + tx * 8u, j0 = P.y0 + ty * 8u;  // wave-uniform tile origin; a lane's pixel is (i0 + lane%8, j0 + lane/8)
+#define RTA_I (i0 + (threadIdx.x & 7u))
+#define RTA_J (j0 + ((threadIdx.x >> 3) & 7u))
+    const bool valid = RTA_I < P.x1 && RTA_J < P.y1;
     const uint32_t s_first = P.spp_begin + chunk * P.chunk_spp;
     const uint32_t s_last = min(s_first + P.chunk_spp, P.spp_end);
-    const uint32_t pixel = j * P.cam.width + i;
 
-    uint32_t s = valid ? s_first : s_last;
-    uint32_t n_rays = 0, n_samples = 0, n_visits = 0;
-    D3 acc = d3(0.0, 0.0, 0.0);
-    D3 o = d3(0.0, 0.0, 0.0), d = d3(0.0, 0.0, 1.0), thr = d3(1.0, 1.0, 1.0);
-    uint32_t depth_left = 0, bounce = 0;
-    while (depth_left != 0 || s < s_last) {
-      if (depth_left == 0) {  // start the next sample of this pixel
-        camera_ray(P.cam, P.seed_lo, P.seed_hi, i, j, s, o, d);
-        thr = d3(1.0, 1.0, 1.0);
-        depth_left = P.cam.max_depth;
-        bounce = 0;
-        ++n_samples;
-        if (depth_left == 0) {  // max_depth 0: every sample is black (src/camera.rs:99-101)
-          ++s;
-          continue;
+    uint32_t s = s_first;
+    uint32_t n_rays = 0, n_steps = 0, n_tests = 0;  // the last two are only kept by the profiling variant
+    uint32_t prof_runs[4] = {0, 0, 0, 0}, prof_lanes[4] = {0, 0, 0, 0};
+    unsigned long long prof_cycles[5] = {0, 0, 0, 0, 0};  // per block, and [4] = the whole item
+    const unsigned long long item_t0 = kProf ? __builtin_amdgcn_s_memtime() : 0ull;
+    D3 acc = d3(0.0, 0.0, 0.0), thr = d3(1.0, 1.0, 1.0);
+    uint32_t depth_left = 0;
+    Trav tr;
+    // What a lane wants next is encoded in tr.cur: an inner node, a leaf, kRefDone (shade),
+    // kRefCamera (start the next sample) or kRefIdle (all samples finished).
+    tr.cur = (valid && s < s_last && P.cam.max_depth != 0) ? kRefCamera : kRefIdle;  // max_depth 0: every sample is black (src/camera.rs:99-101)
+
+    for (;;) {
+      // What does each lane want next?
+      const bool w_inner = !(tr.cur & kRefLeaf);
+      const uint32_t n_inner = (uint32_t)__popcll(__ballot(w_inner));
+      int block;
+      if (n_inner >= P.inner_min) {
+        block = BLK_INNER;
+      } else {
+        const uint32_t n_leaf = (uint32_t)__popcll(__ballot((tr.cur & kRefLeaf) && tr.cur < kRefIdle));
+        const uint32_t n_shade = (uint32_t)__popcll(__ballot(tr.cur == kRefDone));
+        const uint32_t n_camera = (uint32_t)__popcll(__ballot(tr.cur == kRefCamera));
+        if ((n_inner | n_leaf | n_shade | n_camera) == 0u) break;
+        block = BLK_INNER;
+        uint32_t most = n_inner;
+        if (n_leaf > most) {
+          most = n_leaf;
+          block = BLK_LEAF;
+        }
+        if (n_shade > most) {
+          most = n_shade;
+          block = BLK_SHADE;
+        }
+        if (n_camera > most) block = BLK_CAMERA;
+      }
+
+      RTA_T0()
+      if (block == BLK_INNER) {
+        if (w_inner) {
+          RTA_PROF(BLK_INNER)
+          trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
+          if (kProf) ++n_steps;
+          // Most lanes that took a step want another one: take it before counting again.
+          if (!(tr.cur & kRefLeaf)) {
+            trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
+            if (kProf) ++n_steps;
+          }
+        }
+      } else if (block == BLK_LEAF) {
+        if ((tr.cur & kRefLeaf) && tr.cur < kRefIdle) {
+          RTA_PROF(BLK_LEAF)
+          uint32_t tests = 0;
+          trav_leaf_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, t_min, tests);
+          if (kProf) n_tests += tests;
+        }
+      } else if (block == BLK_SHADE) {
+        if (tr.cur == kRefDone) {
+          RTA_PROF(BLK_SHADE)
+          ++n_rays;
+          bool ended = true;
+          if (tr.best < 0) {  // sky, src/camera.rs:103-107
+            double a = (tr.d.y + 1.0) / 2.0;
+            D3 sky = d3((1.0 - a) + a * 0.5, (1.0 - a) + a * 0.7, (1.0 - a) + a * 1.0);
+            acc = acc + thr * sky;
+          } else {
+            const Hit h = make_hit<kAllLds>(tv, tr.best, tr.o, tr.d, tr.t_best);
+            double u0, u1;
+            philox_pair(P.seed_lo, P.seed_hi, RTA_J * P.cam.width + RTA_I, s, P.cam.max_depth - depth_left, DOM_SCATTER, u0, u1);
+            D3 att, nd;
+            if (scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd)) {  // None = absorbed, src/camera.rs:108-110
+              thr = thr * att;
+              if (--depth_left != 0) {  // depth exhausted: the path contributes nothing (src/camera.rs:99-101)
+                trav_begin(tr, tv, h.p, nd, __builtin_inf());  // HitRecord::ray, src/hit.rs:29-31
+                ended = false;
+              }
+            }
+          }
+          if (ended) {
+            ++s;
+            tr.cur = (s < s_last) ? kRefCamera : kRefIdle;
+          }
+        }
+      } else {
+        if (tr.cur == kRefCamera) {  // Camera::get_ray, src/camera.rs:147-148
+          RTA_PROF(BLK_CAMERA)
+          D3 o, d;
+          camera_ray(im.cam, P.cam.width, P.cam.defocus != 0, P.seed_lo, P.seed_hi, RTA_I, RTA_J, s, o, d);
+          thr = d3(1.0, 1.0, 1.0);
+          depth_left = P.cam.max_depth;
+          trav_begin(tr, tv, o, d, __builtin_inf());
         }
       }
-      double t;
-      const int slot = traverse(tv, stack, kWorkgroup, o, d, 1e-3, __builtin_inf(), t, n_visits);  // src/camera.rs:102
-      ++n_rays;
-      if (slot < 0) {  // sky, src/camera.rs:103-107
-        double a = (d.y + 1.0) / 2.0;
-        D3 sky = d3((1.0 - a) + a * 0.5, (1.0 - a) + a * 0.7, (1.0 - a) + a * 1.0);
-        acc = acc + thr * sky;
-        depth_left = 0;
-        ++s;
-        continue;
-      }
-      const Hit h = make_hit(tv, P.sc.aux, slot, o, d, t);
-      double u0, u1;
-      philox_pair(P.seed_lo, P.seed_hi, pixel, s, bounce, DOM_SCATTER, u0, u1);
-      D3 att, nd;
-      if (!scatter(P.sc.materials, h.material, d, h, u0, u1, att, nd)) {  // absorbed, src/camera.rs:108-110
-        depth_left = 0;
-        ++s;
-        continue;
-      }
-      thr = thr * att;
-      o = h.p;  // HitRecord::ray, src/hit.rs:29-31
-      d = nd;
-      ++bounce;
-      if (--depth_left == 0) ++s;  // depth exhausted: contributes nothing (src/camera.rs:99-101)
+      RTA_T1(block)
     }
+    if (kProf) prof_cycles[4] = __builtin_amdgcn_s_memtime() - item_t0;
 
     if (valid) {
+      const uint32_t i = RTA_I, j = RTA_J;
       if (P.direct) {
         double* px = P.out + 3 * ((size_t)j * P.cam.width + i);
         px[0] += acc.x;
@@ -204,13 +329,34 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {
       }
     }
     // one counter update per wave and item
+    const uint32_t n_samples = valid ? s_last - s_first : 0u;  // every sample of the chunk was started (or is black at max_depth 0)
+    unsigned long long c_rays = n_rays, c_samples = n_samples, c_steps = n_steps, c_tests = n_tests;
     for (int off = 32; off > 0; off >>= 1) {
-      n_rays += __shfl_down(n_rays, off);
-      n_samples += __shfl_down(n_samples, off);
+      c_rays += __shfl_down(c_rays, off);
+      c_samples += __shfl_down(c_samples, off);
+      c_steps += __shfl_down(c_steps, off);
+      c_tests += __shfl_down(c_tests, off);
     }
     if (lane == 0) {
-      atomicAdd(&P.counters[1], (unsigned long long)n_rays);
-      atomicAdd(&P.counters[2], (unsigned long long)n_samples);
+      atomicAdd(&P.counters[1], c_rays);
+      atomicAdd(&P.counters[2], c_samples);
+      atomicAdd(&P.counters[3], c_steps);
+      atomicAdd(&P.counters[4], c_tests);
+    }
+    if (kProf) {  // each run was counted by one elected lane: sum over the wave
+      for (int k = 0; k < 4; ++k) {
+        unsigned long long r = prof_runs[k], l = prof_lanes[k];
+        for (int off = 32; off > 0; off >>= 1) {
+          r += __shfl_down(r, off);
+          l += __shfl_down(l, off);
+        }
+        if (lane == 0) {
+          atomicAdd(&P.counters[5 + 2 * k], r);
+          atomicAdd(&P.counters[6 + 2 * k], l);
+        }
+      }
+      if (lane == 0)
+        for (int k = 0; k < 5; ++k) atomicAdd(&P.counters[13 + k], prof_cycles[k]);
     }
   }
 }
@@ -236,8 +382,15 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const double* __rest
 }
 
 // --------------------------------------------------------------- launchers ----
-size_t tree_lds_bytes(const SceneDev& sc, uint32_t wg) {
-  return (size_t)sc.n_nodes_lds * 32 + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.stack_cap * wg * 4;
+size_t lds_node_bytes() { return kLdsNodeQuads * 16; }
+size_t lds_fixed_bytes() { return CAM_DOUBLES * 8; }
+size_t tree_lds_bytes(const SceneDev& sc) {
+  return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * lds_node_bytes() + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
+         (size_t)sc.n_materials_lds * 32 + (size_t)sc.stack_cap * kWorkgroup * 4;
+}
+
+static bool all_in_lds(const SceneDev& sc) {
+  return sc.n_nodes_lds == sc.n_nodes && sc.n_spheres_lds == sc.n_spheres && sc.n_aux_lds == sc.n_spheres && sc.n_materials_lds == sc.n_materials;
 }
 
 static hipError_t allow_lds(const void* fn, size_t bytes) {
@@ -246,15 +399,15 @@ static hipError_t allow_lds(const void* fn, size_t bytes) {
 }
 
 hipError_t launch_trace_batch(const SceneDev& sc, const double* org, const double* dir, size_t n, double t_min, double t_max, int32_t* prim,
-                              double* t, double* normal, uint8_t* front, uint32_t* visits, int max_blocks, hipStream_t stream) {
+                              double* t, double* normal, uint8_t* front, uint32_t* counts, int max_blocks, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  size_t lds = tree_lds_bytes(sc, kWorkgroup);
-  hipError_t e = allow_lds((const void*)trace_batch_kernel, lds);
+  size_t lds = tree_lds_bytes(sc);
+  auto fn = all_in_lds(sc) ? trace_batch_kernel<true> : trace_batch_kernel<false>;
+  hipError_t e = allow_lds((const void*)fn, lds);
   if (e != hipSuccess) return e;
   size_t blocks = (n + kWorkgroup - 1) / kWorkgroup;
   if (blocks > (size_t)max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL(trace_batch_kernel, dim3((unsigned)blocks), dim3(kWorkgroup), lds, stream, sc, org, dir, n, t_min, t_max, prim, t, normal,
-                     front, visits);
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kWorkgroup), lds, stream, sc, org, dir, n, t_min, t_max, prim, t, normal, front, counts);
   return hipGetLastError();
 }
 
@@ -283,11 +436,13 @@ hipError_t launch_primary_rays(const CameraDev& cam, uint64_t seed, const uint32
   return hipGetLastError();
 }
 
-hipError_t launch_render(const RenderParams& P, int blocks, hipStream_t stream) {
-  size_t lds = tree_lds_bytes(P.sc, kWorkgroup);
-  hipError_t e = allow_lds((const void*)render_kernel, lds);
+hipError_t launch_render(const RenderParams& P, int blocks, bool profile, hipStream_t stream) {
+  size_t lds = tree_lds_bytes(P.sc);
+  auto fn = all_in_lds(P.sc) ? (profile ? render_kernel<true, true> : render_kernel<true, false>)
+                             : (profile ? render_kernel<false, true> : render_kernel<false, false>);
+  hipError_t e = allow_lds((const void*)fn, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(kWorkgroup), lds, stream, P);
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kWorkgroup), lds, stream, P);
   return hipGetLastError();
 }
 

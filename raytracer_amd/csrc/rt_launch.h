@@ -7,19 +7,27 @@
 
 namespace rta {
 
-constexpr uint32_t kWorkgroup = 512;  // threads per workgroup of the tree-walking kernels
+// Threads per workgroup of the tree-walking kernels: one workgroup of 16 waves
+// per CU, so that a CU holds a single copy of the scene in its 160 KB of LDS.
+constexpr uint32_t kWorkgroup = 1024;
+constexpr size_t kLdsPerCu = 160 * 1024;
 
 // ------------------------------------------------------------ parameters ----
+// Device arrays of a scene.  Each array may be staged into LDS from its start:
+// entries below the matching n_*_lds count are read from LDS, the rest from
+// global memory.
 struct SceneDev {
-  const float4* nodes;      // 2 x float4 per node (DevNode)
-  const double2* spheres;   // 2 x double2 per slot (DevSphere: cx,cy | cz,r)
-  const double2* aux;       // 1 x double2 per slot: inv_r | (material, prim) packed in the second double's bits
-  const double2* materials; // 4 x double2 per material: (albedo.x, albedo.y) (albedo.z, param) (inv_param, r0) (type bits, 0)
-  uint32_t n_nodes;
+  const float4* nodes;      // 4 x 16 B per inner node (DevNode)
+  const double2* spheres;   // 2 x 16 B per slot (DevSphere: cx,cy | cz,r)
+  const double2* aux;       // 1 x 16 B per slot: 1/r | bits: material index (30) + material type (2), sphere index (32)
+  const double2* materials; // 2 x 16 B per material (DevMaterial)
+  uint32_t n_nodes;         // inner nodes
   uint32_t n_spheres;
-  uint32_t n_nodes_lds;    // nodes [0, n_nodes_lds) are read from LDS
-  uint32_t n_spheres_lds;  // slots [0, n_spheres_lds) are read from LDS (0 or n_spheres)
-  uint32_t stack_cap;      // entries per lane
+  uint32_t n_materials;
+  uint32_t n_nodes_lds, n_spheres_lds, n_aux_lds, n_materials_lds;
+  uint32_t stack_cap;       // traversal stack entries per lane
+  uint32_t root;            // ref of the root: inner node 0, a leaf ref, or 0xffffffff for an empty scene
+  float bound;              // largest |coordinate| of any box plane in the tree
 };
 
 struct CameraDev {
@@ -38,26 +46,37 @@ struct RenderParams {
   uint32_t spp_begin, spp_end;
   uint32_t seed_lo, seed_hi;
   uint32_t n_items;
-  uint32_t direct;  // 1: out is the image and is added to; 0: out is the partial-sum buffer and is overwritten
+  uint32_t direct;     // 1: out is the image and is added to; 0: out is the partial-sum buffer and is overwritten
+  uint32_t inner_min;  // a wave runs the inner-node block while at least this many of its lanes want it
   double* out;
-  unsigned long long* counters;  // [0] next work item, [1] rays, [2] samples
+  unsigned long long* counters;  // see kRenderCounters
 };
 
+// counters: [0] next work item, [1] rays, [2] samples, [3] node steps, [4] sphere tests;
+// profiling variant only: [5+2k] runs and [6+2k] active lanes of block k, [13+k] shader-clock
+// cycles of block k, [17] cycles of whole work items.
+constexpr int kRenderCounters = 18;
 
-// Dynamic LDS a tree-walking kernel needs for this scene.
-size_t tree_lds_bytes(const SceneDev& sc, uint32_t wg);
+// Dynamic LDS a tree-walking kernel needs for this scene (includes the camera block).
+size_t tree_lds_bytes(const SceneDev& sc);
+// LDS footprint of one staged node / of the fixed part (camera constants).
+size_t lds_node_bytes();
+size_t lds_fixed_bytes();
 
 // All launchers enqueue on `stream` and return the launch status; pointers are device pointers.
 hipError_t launch_trace_batch(const SceneDev& sc, const double* org, const double* dir, size_t n, double t_min, double t_max, int32_t* prim,
-                              double* t, double* normal, uint8_t* front, uint32_t* visits, int max_blocks, hipStream_t stream);
+                              double* t, double* normal, uint8_t* front, uint32_t* counts, int max_blocks, hipStream_t stream);
+// mat: material index in the low 30 bits, material type in the top 2.
 hipError_t launch_scatter_batch(const SceneDev& sc, const uint32_t* mat, const double* in_dir, const double* p, const double* normal,
                                 const uint8_t* front, const double* u, size_t n, uint8_t* scattered, double* attenuation, double* out_dir,
                                 hipStream_t stream);
+// boxes: n x 8 floats (lo.xyz, bound, hi.xyz, unused), rounded outwards by the caller; bound = largest |coordinate| of the box.
 hipError_t launch_slab_batch(const float* boxes, const double* org, const double* dir, const double* interval, size_t n, uint8_t* hit,
                              hipStream_t stream);
 hipError_t launch_primary_rays(const CameraDev& cam, uint64_t seed, const uint32_t* ijs, size_t n, double* org, double* dir,
                                hipStream_t stream);
-hipError_t launch_render(const RenderParams& P, int blocks, hipStream_t stream);
+// profile: run the variant that also fills the profiling counters.
+hipError_t launch_render(const RenderParams& P, int blocks, bool profile, hipStream_t stream);
 hipError_t launch_reduce_chunks(const double* partial, double* out, uint32_t n_chunks, uint32_t x0, uint32_t y0, uint32_t tile_w,
                                 uint32_t tile_h, uint32_t width, hipStream_t stream);
 

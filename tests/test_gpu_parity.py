@@ -65,7 +65,9 @@ def test_library_loaded_is_in_tree():
 def test_scene_layout(world):
     info = world.info()
     assert info["n_spheres"] == 488 and info["n_nodes"] == 975 and info["depth"] == 13
-    assert info["n_nodes_in_lds"] == 975 and info["spheres_in_lds"] == 1
+    # one 64-byte device node per split; this scene's tree, spheres, shading data and materials all sit in LDS
+    assert info["n_device_nodes"] == 487 and info["n_nodes_in_lds"] == 487 and info["spheres_in_lds"] == 7
+    assert info["lds_bytes"] <= 160 * 1024
 
 
 def test_device_bvh_equals_oracle_bvh(world, oworld):
