@@ -1,0 +1,67 @@
+"""The HIP path against the committed golden vectors (tests/golden/*.npz,
+written by make_fixtures.py), through the C ABI.  These run without building
+the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def world():
+    z = np.load(os.path.join(GOLD, "scene_rtiow_seed1.npz"))
+    spheres, materials = rt.scene_rtiow(1)
+    assert np.array_equal(spheres, z["spheres"]) and np.array_equal(materials, z["materials"])
+    w = rt.BVH(spheres, materials)
+    yield w
+    w.close()
+
+
+def test_camera_fixture():
+    z = np.load(os.path.join(GOLD, "camera.npz"))
+    for prefix, cfg in (("rtiow_", rt.config_rtiow()), ("default_", rt.Config())):
+        cam = cfg.camera()
+        assert cam.image_height == int(z[prefix + "height"])
+        for k in ("center", "pixel00_loc", "pixel_delta_u", "pixel_delta_v", "defocus_disk_u", "defocus_disk_v"):
+            assert np.array_equal(getattr(cam, k), z[prefix + k])
+
+
+def test_hits_fixture(world):
+    z = np.load(os.path.join(GOLD, "hits_rtiow.npz"))
+    got = world.trace_batch(z["org"], z["dir"])
+    assert np.array_equal(got["prim"], z["prim"])  # closest-hit sphere index: exact
+    hit = z["prim"] >= 0
+    assert np.isinf(got["t"][~hit]).all()
+    assert (np.abs(got["t"][hit] - z["t"][hit]) <= 1e-5 * np.abs(z["t"][hit])).all()  # bar: 1e-5 relative
+    assert np.abs(got["t"][hit] - z["t"][hit]).max() / np.abs(z["t"][hit]).max() < 1e-9  # observed: ~1e-12
+    assert np.abs(got["normal"] - z["normal"]).max() <= 1e-5 and np.array_equal(got["front"], z["front"])
+    org, d = rt.config_rtiow().camera().primary_rays(z["ijs"], seed=12345)
+    n = len(z["ijs"])
+    assert np.abs(org - z["org"][:n]).max() <= 1e-12 and np.abs(d - z["dir"][:n]).max() <= 1e-12
+
+
+def test_scatter_fixture(world):
+    z = np.load(os.path.join(GOLD, "scatter_rtiow.npz"))
+    s, a, d = world.scatter_batch(z["material"], z["in_dir"], z["p"], z["normal"], z["front"], z["u"])
+    assert np.array_equal(s, z["scattered"])
+    assert np.abs(a - z["attenuation"]).max() <= 1e-12 and np.abs(d - z["out_dir"]).max() <= 1e-9
+
+
+def test_image_fixture(world):
+    z = np.load(os.path.join(GOLD, "image_64x36_64spp.npz"))
+    cam = rt.config_rtiow(image_width=64, samples_per_pixel=64, max_depth=50).camera()
+    got, stats = cam.render_sum(world, seed=12345)
+    want = z["rgb_sum"]
+    close = np.abs(got - want).max(axis=2) <= 1e-9 * np.maximum(1.0, np.abs(want).max(axis=2))
+    assert close.mean() >= 0.97  # a last-bit difference can redirect a deep path; almost every pixel agrees to 1e-9
+    assert abs(stats["rays"] - int(z["stats"][0])) <= 0.002 * int(z["stats"][0])
+    q = rt.quantise(got, 64)
+    diff = q.astype(int) - z["ppm_bytes"].astype(int)
+    assert (diff != 0).any(axis=1).mean() <= 0.03
+    mse = (diff.astype(float) ** 2).mean()
+    assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) >= 45.0

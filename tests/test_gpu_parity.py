@@ -355,3 +355,74 @@ def test_hit_and_classes_mirror_reference_usage():
     assert abs(hr.t - 4.0) < 1e-12 and np.abs(hr.normal - [0, 0, -1]).max() < 1e-12
     assert world.hit(rt.Ray.new((0.0, 5.0, -5.0), (0.0, 1.0, 0.0)), rt.Interval(1e-3, float("inf"))) is None
     world.close()
+
+
+# ---- scenes that do not fit in LDS: the top of the tree is staged, the rest is read from HBM ----
+def _field_case(oracle, n_small, seed, p_lam, p_metal, max_fuzz=1.0):
+    spheres, materials = rt.scene_field(seed, n_small, p_lam, p_metal, max_fuzz)
+    return spheres, materials, rt.BVH(spheres, materials), _oracle_scene(oracle, spheres, materials)
+
+
+def _field_camera(width, spp, depth, n_small):
+    half = np.sqrt(n_small) / 2.0
+    return (rt.Config().aspect_ratio(16.0 / 9.0).image_width(width).vfov(35.0).lookfrom((0.9 * half, 0.12 * half + 2.0, 0.9 * half))
+            .lookat((0.0, 0.0, 0.0)).vup((0.0, 1.0, 0.0)).defocus_angle(0.2).focus_dist(float(half)).samples_per_pixel(spp).max_depth(depth))
+
+
+def test_large_scene_uses_global_memory_and_matches_oracle(oracle):
+    n_small = 20000
+    spheres, materials, world, oworld = _field_case(oracle, n_small, 3, 1.0 / 3.0, 1.0 / 3.0)
+    info = world.info()
+    assert info["n_nodes_in_lds"] < info["n_device_nodes"] and info["spheres_in_lds"] == 0
+    for a, b in zip(world.dump(), oworld.bvh_dump()):
+        assert np.array_equal(a, b)
+    cfg = _field_camera(160, 4, 50, n_small)
+    rng = np.random.default_rng(21)
+    n = 1 << 15
+    ijs = np.stack([rng.integers(0, 160, n), rng.integers(0, 90, n), rng.integers(0, 4, n)], axis=1)
+    org, d = oracle.primary_rays(cfg.record().view(oracle.CONFIG_DTYPE), 12345, ijs)
+    ties, rel_t, dn = compare_hits(world.trace_batch(org, d), oworld.trace_batch(org, d))
+    org2, d2 = _secondary_rays(spheres[1:], rng, n)
+    ties2, rel_t2, dn2 = compare_hits(world.trace_batch(org2, d2), oworld.trace_batch(org2, d2))
+    print("20k spheres: primary ties %d rel dt %.2e; secondary ties %d rel dt %.2e" % (ties, rel_t, ties2, rel_t2))
+    assert ties + ties2 <= 8
+    got, stats = cfg.camera().render_sum(world, seed=5)
+    want, ostats = oworld.render(cfg.record().view(oracle.CONFIG_DTYPE), 5, 0, 4, nthreads=8)
+    frac, worst = _pixel_agreement(got, want)
+    print("20k spheres render 160x90x4: %.2f%% pixels equal to 1e-9, rays gpu %d oracle %d" % (100 * frac, stats["rays"], ostats[0]))
+    assert frac >= 0.97 and abs(stats["rays"] - int(ostats[0])) <= 0.002 * int(ostats[0])
+    world.close()
+
+
+def test_glass_metal_deep_bounce_scene(oracle):
+    # the deep-bounce stress mix: half glass, half metal with little fuzz, depth 200
+    n_small = 2500
+    spheres, materials, world, oworld = _field_case(oracle, n_small, 5, 0.0, 0.5, 0.3)
+    cfg = _field_camera(96, 4, 200, n_small)
+    got, stats = cfg.camera().render_sum(world, seed=11)
+    want, ostats = oworld.render(cfg.record().view(oracle.CONFIG_DTYPE), 11, 0, 4, nthreads=8)
+    frac, worst = _pixel_agreement(got, want)
+    print("glass/metal depth 200: %.2f%% pixels equal to 1e-9, mean path length %.2f" % (100 * frac, stats["rays"] / stats["samples"]))
+    assert frac >= 0.95
+    assert abs(stats["rays"] - int(ostats[0])) <= 0.005 * int(ostats[0])
+    world.close()
+
+
+def test_many_spheres_with_one_centre_make_big_leaves(oracle):
+    # No split is possible when all centroids coincide (src/bvh.rs:108-110): one leaf of 300 spheres,
+    # which the device tree cuts into chunks of at most 127.
+    n = 300
+    spheres = np.zeros(n, dtype=rt.SPHERE_DTYPE)
+    materials = np.zeros(1, dtype=rt.MATERIAL_DTYPE)
+    materials["albedo"] = (0.5, 0.5, 0.5)
+    spheres["center"] = (0.0, 0.0, 5.0)
+    spheres["radius"] = np.linspace(0.5, 2.0, n)
+    world = rt.BVH(spheres, materials)
+    oworld = _oracle_scene(oracle, spheres, materials)
+    assert world.info()["n_nodes"] == 1
+    rng = np.random.default_rng(3)
+    org = rng.normal(size=(2048, 3)) * 0.2
+    d = np.array([0.0, 0.0, 1.0]) + rng.normal(size=(2048, 3)) * 0.3
+    d[:, 0] = np.abs(d[:, 0])  # the chunks are visited in stored order for directions with x >= 0
+    compare_hits(world.trace_batch(org, d), oworld.trace_batch(org, d))
+    world.close()

@@ -1,0 +1,164 @@
+"""CPU-only checks of the shipped library's host side: the C ABI exports what
+include/rt.h declares, the host BVH builder reproduces the oracle's (= the
+reference's) tree node for node, the camera, the quantiser and the PPM text match
+the oracle, and compute entry points fail loudly without a GPU."""
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "rt.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(rt.EXPORTS), declared ^ set(rt.EXPORTS)
+    lib = rt._lib.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_no_cpu_fallback():
+    spheres, materials = rt.scene_rtiow(1)
+    try:
+        world = rt.BVH(spheres, materials)
+    except rt.RtError as e:
+        assert e.code == 2 and "hip" in str(e).lower()  # RT_ERR_HIP: fails loudly, computes nothing
+    else:
+        world.close()
+        pytest.skip("a GPU is present")
+
+
+def _same_tree(oracle, spheres):
+    boxes, kind, soc, leaf, depth = rt.host_bvh(spheres)
+    materials = np.zeros(1, dtype=oracle.MATERIAL_DTYPE)
+    sp = spheres.copy()
+    sp["material"] = 0
+    ob, ok, os_, ol = oracle.Scene(sp.view(oracle.SPHERE_DTYPE), materials).bvh_dump()
+    assert np.array_equal(boxes, ob) and np.array_equal(kind, ok) and np.array_equal(soc, os_) and np.array_equal(leaf, ol)
+    return len(kind), depth
+
+
+def test_host_bvh_equals_oracle_bvh(oracle):
+    for seed in (1, 2, 3):
+        n, depth = _same_tree(oracle, rt.scene_rtiow(seed)[0])
+        assert n == 975 or n > 900
+    n, depth = _same_tree(oracle, rt.scene_field(4, 3000, 0.15, 0.15)[0])
+    assert depth < 40
+    rng = np.random.default_rng(0)
+    sp = np.zeros(400, dtype=rt.SPHERE_DTYPE)
+    sp["center"] = rng.uniform(-50, 50, (400, 3))
+    sp["radius"] = rng.uniform(0.01, 8, 400)  # heavily overlapping boxes
+    _same_tree(oracle, sp)
+
+
+def test_host_bvh_edge_cases(oracle):
+    sp = np.zeros(0, dtype=rt.SPHERE_DTYPE)
+    boxes, kind, soc, leaf, depth = rt.host_bvh(sp)
+    assert len(kind) == 1 and kind[0] == 3 and soc[0] == 0  # one empty leaf, as BVH::new builds (src/bvh.rs:108-110)
+    one = np.zeros(1, dtype=rt.SPHERE_DTYPE)
+    one["radius"] = 1.0
+    assert _same_tree(oracle, one)[0] == 1
+    same = np.zeros(5, dtype=rt.SPHERE_DTYPE)  # identical centroids: no valid axis, a single leaf
+    same["radius"] = [1, 2, 3, 4, 5]
+    assert _same_tree(oracle, same)[0] == 1
+    line = np.zeros(64, dtype=rt.SPHERE_DTYPE)  # centroids on one axis only
+    line["center"][:, 0] = np.arange(64)
+    line["radius"] = 0.3
+    n, depth = _same_tree(oracle, line)
+    assert n == 127
+    neg = np.zeros(3, dtype=rt.SPHERE_DTYPE)  # a negative radius bounds like a positive one (src/sphere.rs:50-52)
+    neg["center"] = [[0, 0, 0], [5, 0, 0], [0, 7, 0]]
+    neg["radius"] = [-1, 2, -0.5]
+    _same_tree(oracle, neg)
+
+
+def test_host_bvh_build_time_scales():
+    import time
+
+    sp = rt.scene_field(4, 200000, 0.15, 0.15)[0]
+    t0 = time.time()
+    boxes, kind, soc, leaf, depth = rt.host_bvh(sp)
+    dt = time.time() - t0
+    assert len(leaf) == len(sp) and sorted(leaf.tolist()) == list(range(len(sp)))
+    assert dt < 10.0 and depth <= 64
+
+
+def test_config_mirrors_reference_defaults_and_setters():
+    c = rt.Config()
+    assert c.get("aspect_ratio") == 16.0 / 9.0 and c.get("image_width") == 400 and c.get("samples_per_pixel") == 10
+    assert c.get("max_depth") == 10 and c.get("vfov") == 90.0 and c.get("defocus_angle") == 0.0 and c.get("focus_dist") == 10.0
+    assert c.get("lookfrom").tolist() == [0, 0, -1] and c.get("lookat").tolist() == [0, 0, 0] and c.get("vup").tolist() == [0, 1, 0]
+    d = c.image_width(830).vfov(20.0)
+    assert d.get("image_width") == 830 and c.get("image_width") == 400  # setters take and return by value (src/util.rs:12-16)
+
+
+def test_camera_matches_oracle(oracle):
+    cfgs = [rt.Config(), rt.config_rtiow(), rt.config_rtiow(3840, 1000, 50), rt.Config().image_width(7).aspect_ratio(0.37).vfov(120.0)
+            .lookfrom((1.5, -2.0, 0.25)).lookat((0.1, 0.2, 0.3)).vup((0.1, 0.9, 0.2)).defocus_angle(3.0).focus_dist(2.5)]
+    for cfg in cfgs:
+        cam = cfg.camera()
+        h, want = oracle.camera_derive(cfg.record().view(oracle.CONFIG_DTYPE))
+        assert cam.image_height == h
+        for k, v in want.items():
+            assert np.array_equal(getattr(cam, k), v), k
+    with pytest.raises(rt.RtError):
+        rt.Config().image_width(0).camera()
+    with pytest.raises(rt.RtError):
+        rt.Config().lookfrom((float("nan"), 0, 0)).camera()
+
+
+def test_quantise_and_ppm_match_oracle(oracle):
+    rng = np.random.default_rng(4)
+    w, h, spp = 37, 11, 7
+    rgb = rng.uniform(-0.5, 9.0, (h, w, 3))
+    rgb[0, 0] = [np.nan, np.inf, -np.inf]
+    rgb[0, 1] = [0.0, spp * 1.0, spp * 0.25]
+    assert np.array_equal(rt.quantise(rgb, spp), oracle.quantise(rgb, spp))
+    with tempfile.TemporaryDirectory() as d:
+        a, b = os.path.join(d, "a.ppm"), os.path.join(d, "b.ppm")
+        fd = os.open(a, os.O_WRONLY | os.O_CREAT)
+        rt.write_ppm(fd, rgb, w, h, spp)
+        os.close(fd)
+        oracle.write_ppm(b, rgb, w, h, spp)
+        text = open(a).read()
+        assert text == open(b).read()
+        lines = text.split("\n")
+        assert lines[:3] == ["P3", "%d %d" % (w, h), "255"] and len(lines) == 3 + w * h + 1  # src/camera.rs:139,157-164
+        assert lines[3] == "0 255 0" and lines[4] == "0 255 127"
+    with pytest.raises(ValueError):
+        rt.write_ppm(1, rgb, w + 1, h, spp)
+
+
+def test_rtiow_scene_follows_main_rs():
+    spheres, materials = rt.scene_rtiow(1)
+    assert len(spheres) == 488 and len(materials) == 488  # 4 fixed + 22 x 22 (src/main.rs:45-82)
+    assert spheres["center"][:4].tolist() == [[0, -1000, 0], [0, 1, 0], [-4, 1, 0], [4, 1, 0]]
+    assert spheres["radius"][:4].tolist() == [1000, 1, 1, 1] and (spheres["radius"][4:] == 0.2).all()
+    assert materials["type"][:4].tolist() == [0, 2, 0, 1] and materials["param"][1] == 1.5 and materials["param"][3] == 0.0
+    assert materials["albedo"][2].tolist() == [0.4, 0.2, 0.1] and materials["albedo"][3].tolist() == [0.7, 0.6, 0.5]
+    grid = spheres["center"][4:].reshape(22, 22, 3)
+    a = np.arange(-11, 11)
+    assert ((grid[:, :, 0] >= a[:, None]) & (grid[:, :, 0] < a[:, None] + 0.9)).all()  # a + 0.9 * U[0,1)
+    assert ((grid[:, :, 2] >= a[None, :]) & (grid[:, :, 2] < a[None, :] + 0.9)).all() and (grid[:, :, 1] == 0.2).all()
+    kinds = np.bincount(materials["type"][4:], minlength=3)
+    assert (kinds > 120).all()  # uniform thirds (src/main.rs:64)
+    metal = materials[4:][materials["type"][4:] == 1]
+    assert (metal["albedo"] >= 0.5).all() and (metal["albedo"] <= 1.0).all() and (metal["param"] >= 0).all() and (metal["param"] < 1).all()
+    lam = materials[4:][materials["type"][4:] == 0]
+    assert (lam["albedo"] >= 0).all() and (lam["albedo"] < 1).all() and abs(lam["albedo"].mean() - 0.25) < 0.03  # product of two uniforms
+    assert (materials["param"][4:][materials["type"][4:] == 2] == 1.5).all()
+    again = rt.scene_rtiow(1)
+    assert np.array_equal(again[0], spheres) and not np.array_equal(rt.scene_rtiow(2)[0], spheres)
+
+
+def test_flatten_shares_materials_by_identity():
+    glass = rt.Dielectric().ir(1.5)
+    objs = [rt.Sphere((0, 0, 0), 1.0, glass), rt.Sphere((3, 0, 0), 1.0, glass), rt.Sphere((6, 0, 0), 1.0, rt.Metal((0.5, 0.5, 0.5)).fuzz(0.1))]
+    spheres, materials = rt.flatten(objs)
+    assert spheres["material"].tolist() == [0, 0, 1] and materials["type"].tolist() == [2, 1] and materials["param"].tolist() == [1.5, 0.1]
