@@ -363,3 +363,13 @@ def config_rtiow(image_width=830, samples_per_pixel=750, max_depth=50):
     """The camera of src/main.rs:86-96."""
     return (Config().aspect_ratio(16.0 / 9.0).image_width(image_width).vfov(20.0).lookfrom((13.0, 2.0, 3.0)).lookat((0.0, 0.0, 0.0))
             .vup((0.0, 1.0, 0.0)).defocus_angle(0.6).focus_dist(10.0).samples_per_pixel(samples_per_pixel).max_depth(max_depth))
+
+
+def config_field(n_small, image_width=3840, samples_per_pixel=64, max_depth=50):
+    """A camera pulled back to frame `scene_field(seed, n_small, ...)`: it looks at the middle of the field from
+    above one corner, focused on the middle."""
+    side = float(np.ceil(np.sqrt(n_small)))
+    eye = np.array([0.55 * side, 0.2 * side + 2.0, 0.55 * side])
+    return (Config().aspect_ratio(16.0 / 9.0).image_width(image_width).vfov(40.0).lookfrom(tuple(eye)).lookat((0.0, 0.0, 0.0))
+            .vup((0.0, 1.0, 0.0)).defocus_angle(0.2).focus_dist(float(np.linalg.norm(eye))).samples_per_pixel(samples_per_pixel)
+            .max_depth(max_depth))

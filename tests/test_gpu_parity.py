@@ -426,3 +426,56 @@ def test_many_spheres_with_one_centre_make_big_leaves(oracle):
     d[:, 0] = np.abs(d[:, 0])  # the chunks are visited in stored order for directions with x >= 0
     compare_hits(world.trace_batch(org, d), oworld.trace_batch(org, d))
     world.close()
+
+
+def _brute_force_hits(spheres, org, d, t_min=1e-3):
+    """Closest hit by testing every sphere (src/sphere.rs:30-44), vectorised over spheres, one ray at a time."""
+    c, r = spheres["center"], spheres["radius"]
+    d = d / np.sqrt((d ** 2).sum(axis=1))[:, None]
+    prim = np.full(len(org), -1, dtype=np.int64)
+    t = np.full(len(org), np.inf)
+    for k in range(len(org)):
+        oc = org[k] - c
+        half_b = oc @ d[k]
+        cc = (oc ** 2).sum(axis=1) - r * r
+        disc = half_b * half_b - cc
+        ok = disc >= 0
+        sq = np.sqrt(np.where(ok, disc, 0.0))
+        near, far = -half_b - sq, -half_b + sq
+        root = np.where(near > t_min, near, np.where(far > t_min, far, np.inf))
+        root = np.where(ok, root, np.inf)
+        i = int(np.argmin(root))
+        if np.isfinite(root[i]):
+            prim[k], t[k] = i, root[i]
+    return prim, t
+
+
+def test_full_size_fields_against_brute_force():
+    # the two largest stress sizes (1e5 and 1e6 spheres) without the oracle: the closest hit over the tree
+    # must be the closest hit over all spheres
+    for n_small, seed, n_rays in ((100000, 3, 256), (1000000, 4, 96)):
+        spheres, materials = rt.scene_field(seed, n_small, 0.15, 0.15)
+        world = rt.BVH(spheres, materials)
+        info = world.info()
+        assert info["n_spheres"] == n_small + 1 and info["n_nodes_in_lds"] < info["n_device_nodes"]
+        org, d = rt.config_field(n_small, 64, 4, 50).camera().primary_rays(
+            np.stack([np.arange(n_rays) % 64, (np.arange(n_rays) * 7) % 36, np.arange(n_rays) % 4], axis=1), seed=9)
+        rng = np.random.default_rng(seed)
+        aim = spheres["center"][rng.integers(1, n_small + 1, n_rays)]  # rays aimed near some small sphere from above
+        org2 = aim + np.array([0.0, 6.0, 0.0]) + rng.uniform(-4.0, 4.0, (n_rays, 3))
+        org, d = np.concatenate([org, org2]), np.concatenate([d, aim + rng.normal(size=(n_rays, 3)) * 0.15 - org2])
+        got = world.trace_batch(org, d)
+        prim, t = _brute_force_hits(spheres, org, d)
+        assert (prim >= 1).sum() > n_rays // 4
+        assert np.array_equal(got["prim"], prim)
+        hit = prim >= 0
+        assert (np.abs(got["t"][hit] - t[hit]) <= 1e-9 * t[hit]).all()
+        # and a render of the full tree is the sum of its tiles and sample ranges, bit for bit
+        cam = rt.config_field(n_small, 96, 4, 50).camera()
+        whole, st = cam.render_sum(world, seed=2)
+        parts = np.zeros_like(whole)
+        for tile in ((0, 0, 50, 54), (50, 0, 96, 54)):
+            for s0, s1 in ((0, 1), (1, 4)):
+                cam.render_sum(world, seed=2, spp_begin=s0, spp_end=s1, tile=tile, rgb_sum=parts)
+        assert np.abs(parts - whole).max() <= 1e-12 * np.abs(whole).max()
+        world.close()

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Renders the stress configurations on one GPU and prints one JSON line each:
+scene build time, render time, rays, Mrays/s.  Sample counts are reduced with
+--scale so that a run takes seconds; throughput does not depend on them.
+
+  python tools/run_configs.py [--only c3,c5] [--scale 1.0]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+CONFIGS = {
+    # name: (spheres, p_lambertian, p_metal, max_fuzz, width, spp, depth, scene seed)
+    "c1": (None, 0, 0, 0, 830, 750, 50, 1),
+    "c2": (None, 0, 0, 0, 3840, 1000, 50, 1),
+    "c3": (100000, 1 / 3, 1 / 3, 1.0, 3840, 64, 50, 3),
+    "c4": (1000000, 0.15, 0.15, 1.0, 7680, 32, 50, 4),
+    "c5": (10000, 0.0, 0.5, 0.3, 3840, 128, 200, 5),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="c1,c3,c4,c5")
+    ap.add_argument("--scale", type=float, default=1.0)
+    args = ap.parse_args()
+    import torch
+
+    import raytracer_amd as rt
+
+    for name in args.only.split(","):
+        n, pl, pm, fz, width, spp, depth, seed = CONFIGS[name]
+        spp = max(1, int(spp * args.scale))
+        t0 = time.perf_counter()
+        if n is None:
+            spheres, materials = rt.scene_rtiow(seed)
+            cfg = rt.config_rtiow(width, spp, depth)
+        else:
+            spheres, materials = rt.scene_field(seed, n, pl, pm, fz)
+            cfg = rt.config_field(n, width, spp, depth)
+        t1 = time.perf_counter()
+        world = rt.BVH(spheres, materials)
+        t2 = time.perf_counter()
+        cam = cfg.camera()
+        frame = torch.zeros((cam.image_height, width, 3), dtype=torch.float64, device="cuda")
+        st = cam.render_device(world, frame.data_ptr(), seed=12345)
+        torch.cuda.synchronize()
+        info = world.info()
+        print(json.dumps({
+            "config": name, "spheres": len(spheres), "width": width, "height": cam.image_height, "spp": spp, "depth": depth,
+            "scene_gen_s": t1 - t0, "bvh_build_upload_s": t2 - t1, "host_build_ms": info["build_ms"], "device_nodes": info["n_device_nodes"],
+            "nodes_in_lds": info["n_nodes_in_lds"], "device_bytes": info["device_bytes"], "render_ms": st["kernel_ms"], "launches": st["launches"],
+            "rays": st["rays"], "mean_path_length": st["rays"] / float(st["samples"]), "Mrays_per_s": st["rays"] / st["kernel_ms"] / 1e3,
+            "mean_radiance": float(frame.mean().item()) / spp,
+        }), flush=True)
+        world.close()
+        del frame
+
+
+if __name__ == "__main__":
+    main()
