@@ -65,3 +65,26 @@ def test_image_fixture(world):
     assert (diff != 0).any(axis=1).mean() <= 0.03
     mse = (diff.astype(float) ** 2).mean()
     assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) >= 45.0
+
+
+def test_cxx_driver_prints_the_same_ppm(world, tmp_path):
+    # the C++ mirror of src/main.rs (host/main.cpp) against the ctypes path and the committed image
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(GOLD), "..", "raytracer_amd", "host", "raytracer")
+    p = subprocess.run([exe, "--width", "64", "--spp", "64", "--depth", "50", "--seed", "1", "--render-seed", "12345"],
+                       capture_output=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert p.stderr.startswith(b"Completed in ") and p.stderr.strip().endswith(b"seconds")  # src/camera.rs:156
+    cam = rt.config_rtiow(image_width=64, samples_per_pixel=64, max_depth=50).camera()
+    got, _ = cam.render_sum(world, seed=12345)
+    path = tmp_path / "py.ppm"
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT)
+    rt.write_ppm(fd, got, 64, cam.image_height, 64)
+    os.close(fd)
+    assert p.stdout == open(path, "rb").read()
+    lines = p.stdout.decode().split("\n")
+    assert lines[:3] == ["P3", "64 36", "255"]
+    px = np.array([[int(v) for v in ln.split()] for ln in lines[3:3 + 64 * 36]])
+    z = np.load(os.path.join(GOLD, "image_64x36_64spp.npz"))
+    assert (px != z["ppm_bytes"].astype(int)).any(axis=1).mean() <= 0.03

@@ -162,3 +162,18 @@ def test_flatten_shares_materials_by_identity():
     objs = [rt.Sphere((0, 0, 0), 1.0, glass), rt.Sphere((3, 0, 0), 1.0, glass), rt.Sphere((6, 0, 0), 1.0, rt.Metal((0.5, 0.5, 0.5)).fuzz(0.1))]
     spheres, materials = rt.flatten(objs)
     assert spheres["material"].tolist() == [0, 0, 1] and materials["type"].tolist() == [2, 1] and materials["param"].tolist() == [1.5, 0.1]
+
+
+def test_cxx_driver_fails_loudly_without_a_gpu():
+    import subprocess
+
+    exe = os.path.join(ROOT, "raytracer_amd", "host", "raytracer")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    p = subprocess.run([exe, "--width", "32", "--spp", "1"], capture_output=True, timeout=60)
+    assert p.returncode == 1 and p.stdout == b"" and b"hip" in p.stderr.lower()
