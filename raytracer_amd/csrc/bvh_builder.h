@@ -60,14 +60,6 @@ struct DevSphereAux {
   uint32_t material;  // index into the material table
   uint32_t prim;      // index of the sphere in the caller's array
 };
-struct DevMaterial {
-  double albedo[3];
-  double param;
-  uint32_t type;
-  uint32_t pad[3];
-};
-static_assert(sizeof(DevMaterial) == 48, "DevMaterial must be 48 bytes");
-
 struct FlatBvh {
   std::vector<DevNode> nodes;  // inner nodes, breadth-first: any prefix is the top of the tree
   std::vector<DevSphere> spheres;

@@ -172,7 +172,6 @@ __global__ __launch_bounds__(256) void primary_rays_kernel(CameraDev cam, uint32
 // while at least `inner_min` lanes want it, otherwise the block most lanes are
 // waiting for.  Which block runs when never changes a lane's own sequence of
 // operations, so results do not depend on the policy.
-enum : uint32_t { PH_CAMERA = 0, PH_TRAV = 1, PH_DONE = 2 };
 enum { BLK_CAMERA = 0, BLK_INNER = 1, BLK_LEAF = 2, BLK_SHADE = 3 };
 
 // kProf: also count, per code block, how often it ran and with how many active lanes.

@@ -20,7 +20,7 @@ struct SceneDev {
   const float4* nodes;      // 4 x 16 B per inner node (DevNode)
   const double2* spheres;   // 2 x 16 B per slot (DevSphere: cx,cy | cz,r)
   const double2* aux;       // 1 x 16 B per slot: 1/r | bits: material index (30) + material type (2), sphere index (32)
-  const double2* materials; // 2 x 16 B per material (DevMaterial)
+  const double2* materials; // 2 x 16 B per material: albedo xyz, fuzz | ir, 1/ir, r0
   uint32_t n_nodes;         // inner nodes
   uint32_t n_spheres;
   uint32_t n_materials;
