@@ -333,15 +333,20 @@ __device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, ld
   const bool h1 = box_test(tr.q, f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, tminf, tr.tmaxf);
   const uint32_t ref0 = __float_as_uint(q3.x), ref1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
   const bool swap = ((tr.sgn >> axis) & 1u) != 0u;
-  if (h0 && h1) {
-    stack[tr.sp * stride] = swap ? ref0 : ref1;
-    ++tr.sp;
-    tr.cur = swap ? ref1 : ref0;
-  } else if (h0 || h1) {
-    tr.cur = h0 ? ref0 : ref1;
-  } else {
-    trav_pop(tr, stack, stride);
+  // Selects instead of a three-way branch: only the push and the pop are predicated.
+  const uint32_t near = swap ? ref1 : ref0, far = swap ? ref0 : ref1;
+  const bool both = h0 && h1;
+  uint32_t next = both ? near : (h0 ? ref0 : ref1);
+  if (both) stack[tr.sp * stride] = far;
+  tr.sp += both ? 1u : 0u;
+  if (!(h0 || h1)) {
+    next = kRefDone;
+    if (tr.sp != 0) {
+      --tr.sp;
+      next = stack[tr.sp * stride];
+    }
   }
+  tr.cur = next;
 }
 
 // One leaf: Sphere::hit (src/sphere.rs:29-48) for each of its spheres.  The

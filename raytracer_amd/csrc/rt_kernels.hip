@@ -228,88 +228,106 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
     // kRefCamera (start the next sample) or kRefIdle (all samples finished).
     tr.cur = (valid && s < s_last && P.cam.max_depth != 0) ? kRefCamera : kRefIdle;  // max_depth 0: every sample is black (src/camera.rs:99-101)
 
+    // The wave alternates between a cold part (one SHADE or CAMERA block, which rewrite the whole
+    // lane state) and a hot loop that only walks the tree (INNER and LEAF blocks touch the cursor,
+    // the stack and the closest hit, nothing else), so the hot loop carries few live values around.
+    int block = BLK_CAMERA;
     for (;;) {
-      // What does each lane want next?
-      const bool w_inner = !(tr.cur & kRefLeaf);
-      const uint32_t n_inner = (uint32_t)__popcll(__ballot(w_inner));
-      int block;
-      if (n_inner >= P.inner_min) {
-        block = BLK_INNER;
-      } else {
-        const uint32_t n_leaf = (uint32_t)__popcll(__ballot((tr.cur & kRefLeaf) && tr.cur < kRefIdle));
-        const uint32_t n_shade = (uint32_t)__popcll(__ballot(tr.cur == kRefDone));
-        const uint32_t n_camera = (uint32_t)__popcll(__ballot(tr.cur == kRefCamera));
-        if ((n_inner | n_leaf | n_shade | n_camera) == 0u) break;
-        block = BLK_INNER;
-        uint32_t most = n_inner;
-        if (n_leaf > most) {
-          most = n_leaf;
-          block = BLK_LEAF;
-        }
-        if (n_shade > most) {
-          most = n_shade;
-          block = BLK_SHADE;
-        }
-        if (n_camera > most) block = BLK_CAMERA;
-      }
-
-      RTA_T0()
-      if (block == BLK_INNER) {
-        if (w_inner) {
-          RTA_PROF(BLK_INNER)
-          trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
-          if (kProf) ++n_steps;
-          // Most lanes that took a step want another one: take it before counting again.
-          if (!(tr.cur & kRefLeaf)) {
-            trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
-            if (kProf) ++n_steps;
-          }
-        }
-      } else if (block == BLK_LEAF) {
-        if ((tr.cur & kRefLeaf) && tr.cur < kRefIdle) {
-          RTA_PROF(BLK_LEAF)
-          uint32_t tests = 0;
-          trav_leaf_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, t_min, tests);
-          if (kProf) n_tests += tests;
-        }
-      } else if (block == BLK_SHADE) {
-        if (tr.cur == kRefDone) {
-          RTA_PROF(BLK_SHADE)
-          ++n_rays;
-          bool ended = true;
-          if (tr.best < 0) {  // sky, src/camera.rs:103-107
-            double a = (tr.d.y + 1.0) / 2.0;
-            D3 sky = d3((1.0 - a) + a * 0.5, (1.0 - a) + a * 0.7, (1.0 - a) + a * 1.0);
-            acc = acc + thr * sky;
-          } else {
-            const Hit h = make_hit<kAllLds>(tv, tr.best, tr.o, tr.d, tr.t_best);
-            double u0, u1;
-            philox_pair(P.seed_lo, P.seed_hi, RTA_J * P.cam.width + RTA_I, s, P.cam.max_depth - depth_left, DOM_SCATTER, u0, u1);
-            D3 att, nd;
-            if (scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd)) {  // None = absorbed, src/camera.rs:108-110
-              thr = thr * att;
-              if (--depth_left != 0) {  // depth exhausted: the path contributes nothing (src/camera.rs:99-101)
-                trav_begin(tr, tv, h.p, nd, __builtin_inf());  // HitRecord::ray, src/hit.rs:29-31
-                ended = false;
+      {
+        RTA_T0()
+        if (block == BLK_SHADE) {
+          if (tr.cur == kRefDone) {
+            RTA_PROF(BLK_SHADE)
+            ++n_rays;
+            bool ended = true;
+            if (tr.best < 0) {  // sky, src/camera.rs:103-107
+              double a = (tr.d.y + 1.0) / 2.0;
+              D3 sky = d3((1.0 - a) + a * 0.5, (1.0 - a) + a * 0.7, (1.0 - a) + a * 1.0);
+              acc = acc + thr * sky;
+            } else {
+              const Hit h = make_hit<kAllLds>(tv, tr.best, tr.o, tr.d, tr.t_best);
+              double u0, u1;
+              philox_pair(P.seed_lo, P.seed_hi, RTA_J * P.cam.width + RTA_I, s, P.cam.max_depth - depth_left, DOM_SCATTER, u0, u1);
+              D3 att, nd;
+              if (scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd)) {  // None = absorbed, src/camera.rs:108-110
+                thr = thr * att;
+                if (--depth_left != 0) {  // depth exhausted: the path contributes nothing (src/camera.rs:99-101)
+                  trav_begin(tr, tv, h.p, nd, __builtin_inf());  // HitRecord::ray, src/hit.rs:29-31
+                  ended = false;
+                }
               }
             }
+            if (ended) {
+              ++s;
+              tr.cur = (s < s_last) ? kRefCamera : kRefIdle;
+            }
           }
-          if (ended) {
-            ++s;
-            tr.cur = (s < s_last) ? kRefCamera : kRefIdle;
+        } else {
+          if (tr.cur == kRefCamera) {  // Camera::get_ray, src/camera.rs:147-148
+            RTA_PROF(BLK_CAMERA)
+            D3 o, d;
+            camera_ray(im.cam, P.cam.width, P.cam.defocus != 0, P.seed_lo, P.seed_hi, RTA_I, RTA_J, s, o, d);
+            thr = d3(1.0, 1.0, 1.0);
+            depth_left = P.cam.max_depth;
+            trav_begin(tr, tv, o, d, __builtin_inf());
           }
         }
-      } else {
-        if (tr.cur == kRefCamera) {  // Camera::get_ray, src/camera.rs:147-148
-          RTA_PROF(BLK_CAMERA)
-          D3 o, d;
-          camera_ray(im.cam, P.cam.width, P.cam.defocus != 0, P.seed_lo, P.seed_hi, RTA_I, RTA_J, s, o, d);
-          thr = d3(1.0, 1.0, 1.0);
-          depth_left = P.cam.max_depth;
-          trav_begin(tr, tv, o, d, __builtin_inf());
+        RTA_T1(block)
+      }
+
+      bool finished = false;
+      for (;;) {
+        // What does each lane want next?
+        const bool w_inner = !(tr.cur & kRefLeaf);
+        const uint32_t n_inner = (uint32_t)__builtin_popcountll(__ballot(w_inner));
+        int pick = BLK_INNER;
+        if (n_inner < P.inner_min) {
+          const uint32_t n_leaf = (uint32_t)__builtin_popcountll(__ballot((tr.cur & kRefLeaf) && tr.cur < kRefIdle));
+          const uint32_t n_shade = (uint32_t)__builtin_popcountll(__ballot(tr.cur == kRefDone));
+          const uint32_t n_camera = (uint32_t)__builtin_popcountll(__ballot(tr.cur == kRefCamera));
+          if ((n_inner | n_leaf | n_shade | n_camera) == 0u) {
+            finished = true;
+            break;
+          }
+          uint32_t most = n_inner;
+          if (n_leaf > most) {
+            most = n_leaf;
+            pick = BLK_LEAF;
+          }
+          if (n_shade > most) {
+            most = n_shade;
+            pick = BLK_SHADE;
+          }
+          if (n_camera > most) pick = BLK_CAMERA;
+        }
+        if (pick == BLK_INNER) {
+          RTA_T0()
+          if (w_inner) {
+            RTA_PROF(BLK_INNER)
+            trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
+            if (kProf) ++n_steps;
+            // Most lanes that took a step want another one: take it before counting again.
+            if (!(tr.cur & kRefLeaf)) {
+              trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
+              if (kProf) ++n_steps;
+            }
+          }
+          RTA_T1(BLK_INNER)
+        } else if (pick == BLK_LEAF) {
+          RTA_T0()
+          if ((tr.cur & kRefLeaf) && tr.cur < kRefIdle) {
+            RTA_PROF(BLK_LEAF)
+            uint32_t tests = 0;
+            trav_leaf_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, t_min, tests);
+            if (kProf) n_tests += tests;
+          }
+          RTA_T1(BLK_LEAF)
+        } else {
+          block = pick;
+          break;
         }
       }
-      RTA_T1(block)
+      if (finished) break;
     }
     if (kProf) prof_cycles[4] = __builtin_amdgcn_s_memtime() - item_t0;
 
