@@ -300,6 +300,7 @@ struct Trav {
   float tmaxf;
   uint32_t sgn;  // bit a set: direction negative on axis a
   uint32_t cur, sp;
+  uint32_t tos;  // the top of the stack lives here; `sp` entries below it are in LDS
   int best;
 };
 
@@ -312,16 +313,24 @@ __device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D
   tr.sgn = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
   tr.cur = tv.root;
   tr.sp = 0;
+  tr.tos = kRefDone;  // popping the bottom entry ends the traversal
   tr.best = -1;
 }
 
+// The next node is already in a register when it is needed; the entry below it is
+// fetched from LDS behind the node test that follows.
 __device__ __forceinline__ void trav_pop(Trav& tr, lds_u32* stack, uint32_t stride) {
-  if (tr.sp == 0) {
-    tr.cur = kRefDone;
-  } else {
+  tr.cur = tr.tos;
+  tr.tos = kRefDone;
+  if (tr.sp != 0) {
     --tr.sp;
-    tr.cur = stack[tr.sp * stride];
+    tr.tos = stack[tr.sp * stride];
   }
+}
+__device__ __forceinline__ void trav_push(Trav& tr, lds_u32* stack, uint32_t stride, uint32_t ref) {
+  stack[tr.sp * stride] = tr.tos;
+  ++tr.sp;
+  tr.tos = ref;
 }
 
 // One inner node: test both children, descend into the first one hit.
@@ -336,17 +345,12 @@ __device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, ld
   // Selects instead of a three-way branch: only the push and the pop are predicated.
   const uint32_t near = swap ? ref1 : ref0, far = swap ? ref0 : ref1;
   const bool both = h0 && h1;
-  uint32_t next = both ? near : (h0 ? ref0 : ref1);
-  if (both) stack[tr.sp * stride] = far;
-  tr.sp += both ? 1u : 0u;
-  if (!(h0 || h1)) {
-    next = kRefDone;
-    if (tr.sp != 0) {
-      --tr.sp;
-      next = stack[tr.sp * stride];
-    }
+  if (both) trav_push(tr, stack, stride, far);
+  if (h0 || h1) {
+    tr.cur = both ? near : (h0 ? ref0 : ref1);
+  } else {
+    trav_pop(tr, stack, stride);
   }
-  tr.cur = next;
 }
 
 // One leaf: Sphere::hit (src/sphere.rs:29-48) for each of its spheres.  The

@@ -174,6 +174,14 @@ __global__ __launch_bounds__(256) void primary_rays_kernel(CameraDev cam, uint32
 // operations, so results do not depend on the policy.
 enum { BLK_CAMERA = 0, BLK_INNER = 1, BLK_LEAF = 2, BLK_SHADE = 3 };
 
+// Lanes of the wave for which p holds, as a 32-bit scalar (the barrier keeps the
+// compiler from carrying the count around as a 64-bit value).
+__device__ __forceinline__ uint32_t count_lanes(bool p) {
+  uint32_t n = (uint32_t)__builtin_popcountll(__ballot(p));
+  asm volatile("" : "+s"(n));
+  return n;
+}
+
 // kProf: also count, per code block, how often it ran and with how many active lanes.
 #define RTA_PROF(k)                                              \
   if (kProf) {                                                    \
@@ -279,12 +287,12 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
       for (;;) {
         // What does each lane want next?
         const bool w_inner = !(tr.cur & kRefLeaf);
-        const uint32_t n_inner = (uint32_t)__builtin_popcountll(__ballot(w_inner));
+        const uint32_t n_inner = count_lanes(w_inner);
         int pick = BLK_INNER;
         if (n_inner < P.inner_min) {
-          const uint32_t n_leaf = (uint32_t)__builtin_popcountll(__ballot((tr.cur & kRefLeaf) && tr.cur < kRefIdle));
-          const uint32_t n_shade = (uint32_t)__builtin_popcountll(__ballot(tr.cur == kRefDone));
-          const uint32_t n_camera = (uint32_t)__builtin_popcountll(__ballot(tr.cur == kRefCamera));
+          const uint32_t n_leaf = count_lanes((tr.cur & kRefLeaf) && tr.cur < kRefIdle);
+          const uint32_t n_shade = count_lanes(tr.cur == kRefDone);
+          const uint32_t n_camera = count_lanes(tr.cur == kRefCamera);
           if ((n_inner | n_leaf | n_shade | n_camera) == 0u) {
             finished = true;
             break;
