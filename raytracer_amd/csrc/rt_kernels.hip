@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void primary_rays_kernel(CameraDev cam, uint32
 // waiting for.  Which block runs when never changes a lane's own sequence of
 // operations, so results do not depend on the policy.
 enum { BLK_CAMERA = 0, BLK_INNER = 1, BLK_LEAF = 2, BLK_SHADE = 3 };
+constexpr int kInnerSteps = 2;  // inner-node steps a lane may take per scheduling round
 
 // Lanes of the wave for which p holds, as a 32-bit scalar (the barrier keeps the
 // compiler from carrying the count around as a 64-bit value).
@@ -315,9 +316,12 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
             trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
             if (kProf) ++n_steps;
             // Most lanes that took a step want another one: take it before counting again.
-            if (!(tr.cur & kRefLeaf)) {
-              trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
-              if (kProf) ++n_steps;
+#pragma unroll
+            for (int k = 1; k < kInnerSteps; ++k) {
+              if (!(tr.cur & kRefLeaf)) {
+                trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
+                if (kProf) ++n_steps;
+              }
             }
           }
           RTA_T1(BLK_INNER)
