@@ -205,6 +205,21 @@ int rt_quantise(const double* rgb_sum, size_t n_pixels, uint64_t samples_per_pix
  * then one "r g b\n" line per pixel.  fd is an open file descriptor (1 = stdout). */
 int rt_write_ppm(int fd, const double* rgb_sum, uint32_t width, uint32_t height, uint64_t samples_per_pixel);
 
+/* rt_quantise on the device: rgb_sum_dev (16-byte aligned) and out_dev (2-byte
+ * aligned, 3 bytes per pixel) are device memory; runs on `stream` and waits for
+ * it.  The bytes equal rt_quantise's (division and square root are correctly
+ * rounded in both). */
+int rt_quantise_device(const double* rgb_sum_dev, size_t n_pixels, uint64_t samples_per_pixel, uint8_t* out_dev, void* stream);
+
+/* The text of rt_write_ppm from bytes that are already quantised. */
+int rt_write_ppm_bytes(int fd, const uint8_t* rgb, uint32_t width, uint32_t height);
+
+/* All of `Camera::render` (src/camera.rs:138-165) in one call: renders
+ * cfg->samples_per_pixel samples of every pixel into a frame kept on the device,
+ * quantises it there, copies 3 bytes per pixel back and writes the PPM text to
+ * fd.  The text is what rt_render + rt_write_ppm produce. */
+int rt_render_ppm(const rt_scene* scene, const rt_config* cfg, uint64_t seed, int fd, rt_render_stats* stats);
+
 /* Seeded restatement of the scene of src/main.rs:42-82 (4 fixed spheres and a
  * 22 x 22 grid; 488 spheres, 488 materials).  Both arrays must hold 488 entries. */
 int rt_scene_rtiow(uint64_t seed, rt_sphere* spheres, rt_material* materials);

@@ -2,4 +2,4 @@
 from ._lib import (CAMERA_DTYPE, CONFIG_DTYPE, DIELECTRIC, EXPORTS, LAMBERTIAN, LIB_PATH, MATERIAL_DTYPE, METAL, RECT_DTYPE,
                    RENDER_STATS_DTYPE, SCENE_INFO_DTYPE, SPHERE_DTYPE, RtError)
 from .api import (BVH, Camera, Config, Dielectric, HitRecord, Interval, Lambertian, Material, Metal, Ray, Sphere, config_field, config_rtiow, flatten,
-                  host_bvh, quantise, scene_field, scene_rtiow, slab_batch, write_ppm)
+                  host_bvh, quantise, quantise_device, scene_field, scene_rtiow, slab_batch, write_ppm, write_ppm_bytes)

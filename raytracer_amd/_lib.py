@@ -82,6 +82,9 @@ EXPORTS = [
     "rt_debug_set",
     "rt_quantise",
     "rt_write_ppm",
+    "rt_quantise_device",
+    "rt_write_ppm_bytes",
+    "rt_render_ppm",
     "rt_scene_rtiow",
     "rt_scene_field",
 ]

@@ -291,11 +291,12 @@ class Camera:
         return {k: stats[k][0].item() for k in RENDER_STATS_DTYPE.names}
 
     def render(self, bvh, seed=0, fd=1):
-        """`Camera::render(&self, &BVH)`: PPM text to stdout, elapsed time to stderr."""
-        rgb_sum, stats = self.render_sum(bvh, seed)
-        sys.stderr.write("Completed in %.3f seconds\n" % (stats["kernel_ms"] / 1e3))
-        write_ppm(fd, rgb_sum, self.config.get("image_width"), self.image_height, self.config.get("samples_per_pixel"))
-        return stats
+        """`Camera::render(&self, &BVH)`: PPM text to fd (stdout), elapsed time to stderr.  The frame stays on the
+        device until it is quantised; three bytes per pixel come back."""
+        stats = np.zeros(1, dtype=RENDER_STATS_DTYPE)
+        check(_lib.lib().rt_render_ppm(bvh._h, ptr(self.config.record()), C.c_uint64(seed), C.c_int(fd), ptr(stats)))
+        sys.stderr.write("Completed in %.3f seconds\n" % (stats["kernel_ms"][0] / 1e3))
+        return {k: stats[k][0].item() for k in RENDER_STATS_DTYPE.names}
 
 
 def quantise(rgb_sum, samples_per_pixel):
@@ -304,6 +305,19 @@ def quantise(rgb_sum, samples_per_pixel):
     out = np.zeros((len(rgb), 3), dtype=np.uint8)
     check(_lib.lib().rt_quantise(ptr(rgb), C.c_size_t(len(rgb)), C.c_uint64(samples_per_pixel), ptr(out)))
     return out
+
+
+def quantise_device(rgb_sum_ptr, n_pixels, samples_per_pixel, out_ptr, stream=None):
+    """`write_colour` for a frame in device memory (integer device addresses); 3 bytes per pixel into out_ptr."""
+    check(_lib.lib().rt_quantise_device(C.c_void_p(rgb_sum_ptr), C.c_size_t(n_pixels), C.c_uint64(samples_per_pixel), C.c_void_p(out_ptr),
+                                        C.c_void_p(stream or 0)))
+
+
+def write_ppm_bytes(fd, rgb_bytes, width, height):
+    rgb_bytes = np.ascontiguousarray(rgb_bytes, dtype=np.uint8)
+    if rgb_bytes.size != width * height * 3:
+        raise ValueError("rgb_bytes must hold width x height x 3 bytes")
+    check(_lib.lib().rt_write_ppm_bytes(C.c_int(fd), ptr(rgb_bytes), C.c_uint32(width), C.c_uint32(height)))
 
 
 def write_ppm(fd, rgb_sum, width, height, samples_per_pixel):

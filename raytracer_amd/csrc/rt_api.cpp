@@ -565,6 +565,43 @@ int rt_quantise(const double* rgb_sum, size_t n_pixels, uint64_t spp, uint8_t* o
   return RT_OK;
 }
 
+int rt_quantise_device(const double* rgb_sum_dev, size_t n_pixels, uint64_t spp, uint8_t* out_dev, void* stream) {
+  if (n_pixels && (!rgb_sum_dev || !out_dev)) return fail(RT_ERR_INVALID, "rt_quantise_device: null buffer");
+  if (((uintptr_t)rgb_sum_dev & 15) || ((uintptr_t)out_dev & 1)) return fail(RT_ERR_INVALID, "rt_quantise_device: rgb_sum must be 16-byte and out 2-byte aligned");
+  if (spp == 0) return fail(RT_ERR_INVALID, "rt_quantise_device: samples_per_pixel is 0");
+  RT_HIP(launch_quantise(rgb_sum_dev, 3 * n_pixels, spp, out_dev, (hipStream_t)stream));
+  RT_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return RT_OK;
+}
+
+int rt_write_ppm_bytes(int fd, const uint8_t* rgb, uint32_t width, uint32_t height) {
+  if (!rgb && width && height) return fail(RT_ERR_INVALID, "rt_write_ppm_bytes: rgb is null");
+  if (!write_ppm_bytes(fd, rgb, width, height)) return fail(RT_ERR_IO, "rt_write_ppm_bytes: write failed");
+  return RT_OK;
+}
+
+int rt_render_ppm(const rt_scene* sc, const rt_config* cfg, uint64_t seed, int fd, rt_render_stats* stats) {
+  if (!sc) return fail(RT_ERR_INVALID, "rt_render_ppm: scene is null");
+  CameraDev cam;
+  int rc = make_camera_dev(cfg, &cam, "rt_render_ppm");
+  if (rc) return rc;
+  if (cfg->samples_per_pixel == 0 || cfg->samples_per_pixel > 0xffffffffull) return fail(RT_ERR_INVALID, "rt_render_ppm: samples_per_pixel must be in 1 .. 2^32-1");
+  DeviceGuard g(sc->device);
+  RT_HIP(g.status);
+  const size_t n_px = (size_t)cam.width * cam.height;
+  DevBuf img, bytes;
+  RT_HIP(img.alloc(n_px * 24));
+  RT_HIP(bytes.alloc(n_px * 3 + 2));
+  RT_HIP(hipMemset(img.p, 0, n_px * 24));
+  rc = rt_render_device(sc, cfg, seed, 0, (uint32_t)cfg->samples_per_pixel, nullptr, img.as<double>(), nullptr, stats);
+  if (rc) return rc;
+  RT_HIP(launch_quantise(img.as<double>(), 3 * n_px, cfg->samples_per_pixel, bytes.as<uint8_t>(), nullptr));
+  std::vector<uint8_t> host(3 * n_px);
+  RT_HIP(hipMemcpy(host.data(), bytes.p, 3 * n_px, hipMemcpyDeviceToHost));
+  if (!write_ppm_bytes(fd, host.data(), cam.width, cam.height)) return fail(RT_ERR_IO, "rt_render_ppm: write failed");
+  return RT_OK;
+}
+
 int rt_write_ppm(int fd, const double* rgb_sum, uint32_t width, uint32_t height, uint64_t spp) {
   if (!rgb_sum && width && height) return fail(RT_ERR_INVALID, "rt_write_ppm: rgb_sum is null");
   if (!write_ppm(fd, rgb_sum, width, height, spp)) return fail(RT_ERR_IO, "rt_write_ppm: write failed");

@@ -2,8 +2,11 @@
 
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace rta {
@@ -119,48 +122,82 @@ void quantise(const double* rgb_sum, size_t n_pixels, uint64_t spp, uint8_t* out
   }
 }
 
-bool write_ppm(int fd, const double* rgb_sum, uint32_t width, uint32_t height, uint64_t spp) {
-  std::vector<char> buf;
-  buf.reserve(1 << 20);
-  auto flush = [&]() {
-    size_t off = 0;
-    while (off < buf.size()) {
-      ssize_t w = ::write(fd, buf.data() + off, buf.size() - off);
-      if (w <= 0) return false;
-      off += (size_t)w;
-    }
-    buf.clear();
-    return true;
-  };
-  auto put_u = [&](unsigned v) {
-    char tmp[12];
-    int n = 0;
-    do {
-      tmp[n++] = (char)('0' + v % 10);
-      v /= 10;
-    } while (v);
-    while (n) buf.push_back(tmp[--n]);
-  };
-  const char* head = "P3\n";  // src/camera.rs:139
-  buf.insert(buf.end(), head, head + 3);
-  put_u(width);
-  buf.push_back(' ');
-  put_u(height);
-  const char* tail = "\n255\n";
-  buf.insert(buf.end(), tail, tail + 5);
-  const size_t n = (size_t)width * height;
-  for (size_t i = 0; i < n; ++i) {  // rows top to bottom, src/camera.rs:157-164
-    uint8_t q[3];
-    quantise(rgb_sum + 3 * i, 1, spp, q);
-    put_u(q[0]);
-    buf.push_back(' ');
-    put_u(q[1]);
-    buf.push_back(' ');
-    put_u(q[2]);
-    buf.push_back('\n');
-    if (buf.size() > (1 << 20) - 64 && !flush()) return false;
+namespace {
+bool write_all(int fd, const char* p, size_t n) {
+  while (n) {
+    ssize_t w = ::write(fd, p, n);
+    if (w <= 0) return false;
+    p += w;
+    n -= (size_t)w;
   }
-  return flush();
+  return true;
+}
+// "0".."255" as text, 4 bytes each (digits then padding), and their lengths.
+struct ByteText {
+  char text[256][4];
+  uint8_t len[256];
+  ByteText() {
+    for (int v = 0; v < 256; ++v) {
+      int n = std::snprintf(text[v], 4, "%d", v);
+      len[v] = (uint8_t)n;
+    }
+  }
+};
+// Formats pixels [begin, end) as "r g b\n" lines into out (at most 12 bytes per pixel); returns the length.
+size_t format_pixels(const ByteText& bt, const uint8_t* rgb, size_t begin, size_t end, char* out) {
+  char* o = out;
+  for (size_t i = begin; i < end; ++i) {
+    const uint8_t* p = rgb + 3 * i;
+    for (int c = 0; c < 3; ++c) {
+      const uint8_t v = p[c];
+      std::memcpy(o, bt.text[v], 4);  // copies padding too; the next write overwrites it
+      o += bt.len[v];
+      *o++ = c == 2 ? '\n' : ' ';
+    }
+  }
+  return (size_t)(o - out);
+}
+}  // namespace
+
+// Header of src/camera.rs:139, then one line per pixel, rows top to bottom (src/camera.rs:157-164).
+// The pixels are formatted by a few threads into per-thread buffers that are written in order.
+bool write_ppm_bytes(int fd, const uint8_t* rgb, uint32_t width, uint32_t height) {
+  static const ByteText bt;
+  char head[64];
+  int hn = std::snprintf(head, sizeof(head), "P3\n%u %u\n255\n", width, height);
+  if (!write_all(fd, head, (size_t)hn)) return false;
+  const size_t n = (size_t)width * height;
+  const size_t batch = 1 << 18;  // pixels per buffer: 3 MB of text at most
+  unsigned hw = std::thread::hardware_concurrency();
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)8, (n + batch - 1) / batch}));
+  std::vector<std::vector<char>> bufs(n_threads, std::vector<char>(batch * 12 + 4));
+  std::vector<size_t> lens(n_threads);
+  for (size_t base = 0; base < n; base += batch * n_threads) {
+    std::vector<std::thread> workers;
+    size_t used = 0;
+    for (size_t t = 0; t < n_threads; ++t) {
+      const size_t b = base + t * batch;
+      if (b >= n) break;
+      const size_t e = std::min(n, b + batch);
+      ++used;
+      if (n_threads == 1) {
+        lens[t] = format_pixels(bt, rgb, b, e, bufs[t].data());
+      } else {
+        workers.emplace_back([&, t, b, e]() { lens[t] = format_pixels(bt, rgb, b, e, bufs[t].data()); });
+      }
+    }
+    for (auto& w : workers) w.join();
+    for (size_t t = 0; t < used; ++t)
+      if (!write_all(fd, bufs[t].data(), lens[t])) return false;
+  }
+  return true;
+}
+
+bool write_ppm(int fd, const double* rgb_sum, uint32_t width, uint32_t height, uint64_t spp) {
+  const size_t n = (size_t)width * height;
+  std::vector<uint8_t> bytes(3 * n);
+  quantise(rgb_sum, n, spp, bytes.data());
+  return write_ppm_bytes(fd, bytes.data(), width, height);
 }
 
 namespace {

@@ -22,6 +22,8 @@ void camera_derive(const rt_config& cfg, rt_camera* out);
 void quantise(const double* rgb_sum, size_t n_pixels, uint64_t spp, uint8_t* out);
 // Returns false on a write error.
 bool write_ppm(int fd, const double* rgb_sum, uint32_t width, uint32_t height, uint64_t spp);
+// The same text from bytes that are already quantised (3 per pixel).
+bool write_ppm_bytes(int fd, const uint8_t* rgb, uint32_t width, uint32_t height);
 
 void scene_rtiow(uint64_t seed, rt_sphere* spheres, rt_material* materials);
 void scene_field(uint64_t seed, size_t n_small, double p_lambertian, double p_metal, double max_fuzz, rt_sphere* spheres,

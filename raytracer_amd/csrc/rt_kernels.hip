@@ -410,6 +410,27 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const double* __rest
   px[2] += b;
 }
 
+// ---------------------------------------------------------------- quantise ----
+// write_colour (src/camera.rs:85-95) for every component of the frame: divide by the
+// sample count, gamma 2 (sqrt), clamp to [0,1], scale by 255, truncate.  Division and
+// square root are correctly rounded in f64, so the bytes equal the host's.  Two
+// components per lane and step: 16-byte loads, 2-byte stores.
+__global__ __launch_bounds__(256) void quantise_kernel(const double* __restrict__ rgb_sum, size_t n_components, double spp,
+                                                       uint8_t* __restrict__ out) {
+  const size_t n_pairs = n_components / 2;
+  const f64x2* in2 = reinterpret_cast<const f64x2*>(rgb_sum);
+  auto q = [spp](double x) -> uint32_t {
+    double g = sqrt(x / spp);
+    double v = 255.0 * fmin(fmax(g, 0.0), 1.0);  // fmin/fmax drop a NaN operand: NaN -> 0, as Interval::clamp then `as u8` give
+    return !(v > 0.0) ? 0u : v >= 255.0 ? 255u : (uint32_t)v;
+  };
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n_pairs; k += (size_t)gridDim.x * 256) {
+    const f64x2 v = in2[k];
+    reinterpret_cast<uint16_t*>(out)[k] = (uint16_t)(q(v.x) | (q(v.y) << 8));
+  }
+  if ((n_components & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n_components - 1] = (uint8_t)q(rgb_sum[n_components - 1]);
+}
+
 // --------------------------------------------------------------- launchers ----
 size_t lds_node_bytes() { return kLdsNodeQuads * 16; }
 size_t lds_fixed_bytes() { return CAM_DOUBLES * 8; }
@@ -481,6 +502,15 @@ hipError_t launch_reduce_chunks(const double* partial, double* out, uint32_t n_c
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, out, n_chunks, x0, y0, tile_w,
                      tile_h, width);
+  return hipGetLastError();
+}
+
+hipError_t launch_quantise(const double* rgb_sum, size_t n_components, uint64_t spp, uint8_t* out, hipStream_t stream) {
+  if (n_components == 0) return hipSuccess;
+  size_t blocks = (n_components / 2 + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(quantise_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rgb_sum, n_components, (double)spp, out);
   return hipGetLastError();
 }
 

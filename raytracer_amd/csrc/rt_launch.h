@@ -79,5 +79,7 @@ hipError_t launch_primary_rays(const CameraDev& cam, uint64_t seed, const uint32
 hipError_t launch_render(const RenderParams& P, int blocks, bool profile, hipStream_t stream);
 hipError_t launch_reduce_chunks(const double* partial, double* out, uint32_t n_chunks, uint32_t x0, uint32_t y0, uint32_t tile_w,
                                 uint32_t tile_h, uint32_t width, hipStream_t stream);
+// out (bytes, 2-byte aligned) = write_colour of each of the n_components sums.
+hipError_t launch_quantise(const double* rgb_sum, size_t n_components, uint64_t spp, uint8_t* out, hipStream_t stream);
 
 }  // namespace rta

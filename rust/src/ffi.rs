@@ -108,5 +108,6 @@ extern "C" {
         normal: *mut f64,
         front_face: *mut u8,
     ) -> c_int;
+    pub fn rt_render_ppm(scene: *const rt_scene, cfg: *const rt_config, seed: u64, fd: c_int, stats: *mut rt_render_stats) -> c_int;
     pub fn rt_write_ppm(fd: c_int, rgb_sum: *const f64, width: u32, height: u32, samples_per_pixel: u64) -> c_int;
 }

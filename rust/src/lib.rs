@@ -94,6 +94,15 @@ impl Scene {
     }
 }
 
+impl Scene {
+    /// All of `Camera::render` in one call: render, quantise on the device, PPM text to stdout.
+    pub fn render_ppm(&self, cfg: &ffi::rt_config, seed: u64) -> Result<ffi::rt_render_stats, Error> {
+        let mut stats = ffi::rt_render_stats::default();
+        check(unsafe { ffi::rt_render_ppm(self.0, cfg, seed, 1, &mut stats) })?;
+        Ok(stats)
+    }
+}
+
 impl Drop for Scene {
     fn drop(&mut self) {
         unsafe { ffi::rt_scene_destroy(self.0) };

@@ -88,3 +88,45 @@ def test_cxx_driver_prints_the_same_ppm(world, tmp_path):
     px = np.array([[int(v) for v in ln.split()] for ln in lines[3:3 + 64 * 36]])
     z = np.load(os.path.join(GOLD, "image_64x36_64spp.npz"))
     assert (px != z["ppm_bytes"].astype(int)).any(axis=1).mean() <= 0.03
+
+
+def test_device_quantise_equals_host_quantise():
+    # write_colour (src/camera.rs:85-95) on the device must give the host's bytes, including at the
+    # values where 255*sqrt(x/spp) crosses an integer and for NaN, infinities and negatives
+    import torch
+
+    rng = np.random.default_rng(8)
+    spp = 7
+    k = np.arange(0, 256, dtype=np.float64)
+    edge = (k / 255.0) ** 2 * spp  # sums whose gamma-corrected value sits on a byte boundary
+    edges = np.concatenate([np.nextafter(edge, -np.inf), edge, np.nextafter(edge, np.inf),
+                            np.nextafter(np.nextafter(edge, np.inf), np.inf), np.nextafter(np.nextafter(edge, -np.inf), -np.inf)])
+    special = np.array([np.nan, np.inf, -np.inf, -1.0, -0.0, 0.0, 1e-320, 1e-300, 1e300, spp * 1.0, spp * (1 - 2 ** -53)])
+    vals = np.concatenate([edges, special, rng.uniform(0, spp, 3_000_000), rng.uniform(0, 3 * spp, 200_000), 10.0 ** rng.uniform(-12, 2, 500_000)])
+    vals = vals[: len(vals) // 3 * 3].copy()
+    n_px = len(vals) // 3
+    want = rt.quantise(vals.reshape(-1, 3), spp)
+    dev = torch.from_numpy(vals).cuda()
+    out = torch.zeros(3 * n_px + 2, dtype=torch.uint8, device="cuda")
+    rt.quantise_device(dev.data_ptr(), n_px, spp, out.data_ptr())
+    got = out[: 3 * n_px].cpu().numpy().reshape(-1, 3)
+    assert np.array_equal(got, want)
+    odd = vals[:5 * 3 + 0][: 15].copy()  # an odd number of components goes through the tail path
+    dev = torch.from_numpy(odd).cuda()
+    out = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    rt.quantise_device(dev.data_ptr(), 5, spp, out.data_ptr())
+    assert np.array_equal(out[:15].cpu().numpy().reshape(-1, 3), rt.quantise(odd.reshape(-1, 3), spp))
+
+
+def test_render_ppm_equals_render_then_write(world, tmp_path):
+    cfg = rt.config_rtiow(image_width=96, samples_per_pixel=8, max_depth=50)
+    cam = cfg.camera()
+    a, b = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
+    fd = os.open(a, os.O_WRONLY | os.O_CREAT)
+    stats = cam.render(world, seed=3, fd=fd)
+    os.close(fd)
+    got, st2 = cam.render_sum(world, seed=3)
+    fd = os.open(b, os.O_WRONLY | os.O_CREAT)
+    rt.write_ppm(fd, got, 96, cam.image_height, 8)
+    os.close(fd)
+    assert open(a, "rb").read() == open(b, "rb").read() and stats["rays"] == st2["rays"]
