@@ -4,6 +4,8 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <memory>
+#include <thread>
 
 namespace rta {
 namespace {
@@ -42,47 +44,136 @@ inline int choose_bucket(double min_t, double max_t, double t) {
   return (int)scaled;
 }
 
+// Work below this many spheres stays on the calling thread.
+const size_t kParallelGrain = 16384;
+
+inline unsigned host_threads() {
+  unsigned hw = std::thread::hardware_concurrency();
+  return std::max(1u, std::min(hw ? hw : 1u, 16u));
+}
+
+// Runs f(part, begin, end) over [lo, hi) cut into `parts` contiguous pieces, one thread each.
+template <class F>
+void for_parts(size_t lo, size_t hi, unsigned parts, F f) {
+  if (parts <= 1) {
+    f(0u, lo, hi);
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t n = hi - lo;
+  for (unsigned p = 1; p < parts; ++p) th.emplace_back(f, p, lo + n * p / parts, lo + n * (p + 1) / parts);
+  f(0u, lo, lo + n / parts);
+  for (auto& t : th) t.join();
+}
+
+// A subtree in the reference's pre-order layout, possibly with holes: where a large node's
+// children were built by two threads, their subtrees hang off the hole that follows the node and
+// are spliced in once, at the end.  `total` counts the nodes including those in holes.
+struct Subtree {
+  struct Hole {
+    size_t pos;  // the pieces go before nodes[pos]
+    std::unique_ptr<Subtree> left, right;
+  };
+  std::vector<HostNode> nodes;
+  std::vector<Hole> holes;
+  size_t total = 0;
+  uint32_t depth = 0;
+  void flatten_into(std::vector<HostNode>& dst) const {
+    size_t h = 0;
+    for (size_t i = 0; i <= nodes.size(); ++i) {
+      while (h < holes.size() && holes[h].pos == i) {
+        holes[h].left->flatten_into(dst);
+        holes[h].right->flatten_into(dst);
+        ++h;
+      }
+      if (i < nodes.size()) dst.push_back(nodes[i]);
+    }
+  }
+};
+
+struct BucketSet {
+  Box box[kBuckets];
+  uint64_t count[kBuckets];
+  void clear() {
+    for (int b = 0; b < kBuckets; ++b) {
+      box[b] = empty_box();
+      count[b] = 0;
+    }
+  }
+};
+
+// The binned-SAH object-split builder of src/bvh.rs:92-266.  Large nodes are binned by several
+// threads (box unions and counts are exact and order-independent, so the tree is the same as a
+// serial build's) and large left subtrees are built by their own thread.
 struct Builder {
   std::vector<Box> prim_box;            // Sphere::aabb, src/sphere.rs:50-52
   std::vector<double> centroid[3];      // AABB::centroid, src/aabb.rs:23-25
   std::vector<uint64_t> idx, tmp;
-  HostBvh out;
+  size_t grain = kParallelGrain;
+  unsigned max_threads = 1;
 
-  void build(size_t lo, size_t hi, uint32_t depth) {
+  void build(size_t lo, size_t hi, uint32_t depth, Subtree& out) {
     const size_t n = hi - lo;
     out.depth = std::max(out.depth, depth);
-    Box box = empty_box();
-    for (size_t k = lo; k < hi; ++k) grow(box, prim_box[idx[k]]);
+    const unsigned parts = n >= 2 * kParallelGrain ? (unsigned)std::min<size_t>(max_threads, n / kParallelGrain) : 1u;
 
-    // Bounds of the centroids (AABB::bounding_box, src/aabb.rs:40-46).
-    double cmin[3] = {kInf, kInf, kInf}, cmax[3] = {-kInf, -kInf, -kInf};
-    if (n > 0) {
-      for (int a = 0; a < 3; ++a) cmin[a] = cmax[a] = centroid[a][idx[lo]];
-      for (size_t k = lo + 1; k < hi; ++k)
+    // Node box and bounds of the centroids (AABB::bounding_box, src/aabb.rs:40-46).
+    struct Bounds {
+      Box box;
+      double cmin[3], cmax[3];
+    };
+    Bounds pb1;
+    std::vector<Bounds> pbv(parts > 1 ? parts : 0);
+    Bounds* pb = parts > 1 ? pbv.data() : &pb1;
+    for_parts(lo, hi, parts, [&](unsigned p, size_t b0, size_t b1) {
+      Bounds r{empty_box(), {kInf, kInf, kInf}, {-kInf, -kInf, -kInf}};
+      for (size_t k = b0; k < b1; ++k) {
+        const uint64_t i = idx[k];
+        grow(r.box, prim_box[i]);
         for (int a = 0; a < 3; ++a) {
-          double c = centroid[a][idx[k]];
-          cmin[a] = std::fmin(cmin[a], c);
-          cmax[a] = std::fmax(cmax[a], c);
+          const double c = centroid[a][i];
+          r.cmin[a] = std::fmin(r.cmin[a], c);
+          r.cmax[a] = std::fmax(r.cmax[a], c);
         }
+      }
+      pb[p] = r;
+    });
+    Box box = pb[0].box;
+    double cmin[3], cmax[3];
+    for (int a = 0; a < 3; ++a) cmin[a] = pb[0].cmin[a], cmax[a] = pb[0].cmax[a];
+    for (unsigned p = 1; p < parts; ++p) {
+      grow(box, pb[p].box);
+      for (int a = 0; a < 3; ++a) {
+        cmin[a] = std::fmin(cmin[a], pb[p].cmin[a]);
+        cmax[a] = std::fmax(cmax[a], pb[p].cmax[a]);
+      }
     }
 
     bool have = false;
     int best_axis = 0, best_split = 0;
     double best_cost = 0.0;
     const double node_area = surface_area(box);
+    BucketSet sets1;
+    std::vector<BucketSet> setsv(parts > 1 ? parts : 0);
+    BucketSet* sets = parts > 1 ? setsv.data() : &sets1;
     for (int axis = 0; axis < 3; ++axis) {  // iter_bounds_axes, src/bvh.rs:196-201
       if (!((cmax[axis] - cmin[axis]) > 0.0)) continue;
-      Box bbox[kBuckets];
-      uint64_t bcount[kBuckets];
-      for (int b = 0; b < kBuckets; ++b) {
-        bbox[b] = empty_box();
-        bcount[b] = 0;
-      }
-      for (size_t k = lo; k < hi; ++k) {
-        int b = choose_bucket(cmin[axis], cmax[axis], centroid[axis][idx[k]]);
-        bcount[b]++;
-        grow(bbox[b], prim_box[idx[k]]);
-      }
+      for_parts(lo, hi, parts, [&](unsigned p, size_t b0, size_t b1) {
+        BucketSet& s = sets[p];
+        s.clear();
+        for (size_t k = b0; k < b1; ++k) {
+          const uint64_t i = idx[k];
+          int b = choose_bucket(cmin[axis], cmax[axis], centroid[axis][i]);
+          s.count[b]++;
+          grow(s.box[b], prim_box[i]);
+        }
+      });
+      BucketSet& all = sets[0];
+      for (unsigned p = 1; p < parts; ++p)
+        for (int b = 0; b < kBuckets; ++b) {
+          all.count[b] += sets[p].count[b];
+          grow(all.box[b], sets[p].box[b]);
+        }
       // Suffix unions, then one forward sweep: the same boxes and counts that
       // combine_buckets (src/bvh.rs:260-266) yields for every split point,
       // because min/max are exact and associative.
@@ -91,15 +182,15 @@ struct Builder {
       suffix[kBuckets] = empty_box();
       suffix_n[kBuckets] = 0;
       for (int b = kBuckets - 1; b >= 0; --b) {
-        suffix[b] = bbox[b];
+        suffix[b] = all.box[b];
         grow(suffix[b], suffix[b + 1]);
-        suffix_n[b] = bcount[b] + suffix_n[b + 1];
+        suffix_n[b] = all.count[b] + suffix_n[b + 1];
       }
       Box prefix = empty_box();
       uint64_t prefix_n = 0;
       for (int i = 1; i < kBuckets; ++i) {
-        grow(prefix, bbox[i - 1]);
-        prefix_n += bcount[i - 1];
+        grow(prefix, all.box[i - 1]);
+        prefix_n += all.count[i - 1];
         double cost = kSplitCost + kLeafCost * ((double)prefix_n * surface_area(prefix) + (double)suffix_n[i] * surface_area(suffix[i])) /
                                        node_area;  // src/bvh.rs:218-226
         if (!have || total_order_key(cost) < total_order_key(best_cost)) {
@@ -112,27 +203,40 @@ struct Builder {
     }
 
     if (have && best_cost < kLeafCost * (double)n) {  // src/bvh.rs:124
-      // Stable partition keeps both sides in ascending sphere order.
+      // Stable partition keeps both sides in ascending sphere order; tmp[lo, hi) is this node's scratch.
       size_t nl = 0, nr = 0;
       for (size_t k = lo; k < hi; ++k) {
         int b = choose_bucket(cmin[best_axis], cmax[best_axis], centroid[best_axis][idx[k]]);
         if (b < best_split)
           idx[lo + nl++] = idx[k];
         else
-          tmp[nr++] = idx[k];
+          tmp[lo + nr++] = idx[k];
       }
-      std::copy(tmp.begin(), tmp.begin() + nr, idx.begin() + lo + nl);
-      size_t me = out.nodes.size();
+      std::copy(tmp.begin() + lo, tmp.begin() + lo + nr, idx.begin() + lo + nl);
+      const size_t me = out.nodes.size(), me_total = out.total;
       out.nodes.push_back(HostNode{box, best_axis, 0, 0, 0});
-      build(lo, lo + nl, depth + 1);
-      out.nodes[me].skip = out.nodes.size() - me;  // src/bvh.rs:126-130
-      build(lo + nl, hi, depth + 1);
+      out.total++;
+      if (nl >= grain && nr >= grain / 4) {
+        Subtree::Hole hole{out.nodes.size(), std::make_unique<Subtree>(), std::make_unique<Subtree>()};
+        Subtree &left = *hole.left, &right = *hole.right;
+        std::thread worker([&]() { build(lo, lo + nl, depth + 1, left); });
+        build(lo + nl, hi, depth + 1, right);
+        worker.join();
+        out.nodes[me].skip = left.total + 1;  // src/bvh.rs:126-130
+        out.total += left.total + right.total;
+        out.depth = std::max({out.depth, left.depth, right.depth});
+        out.holes.push_back(std::move(hole));
+      } else {
+        build(lo, lo + nl, depth + 1, out);
+        out.nodes[me].skip = out.total - me_total;
+        build(lo + nl, hi, depth + 1, out);
+      }
       return;
     }
-    // Leaf (src/bvh.rs:108-110,137)
-    HostNode leaf{box, 3, 0, out.leaf_indices.size(), n};
-    for (size_t k = lo; k < hi; ++k) out.leaf_indices.push_back(idx[k]);
-    out.nodes.push_back(leaf);
+    // Leaf (src/bvh.rs:108-110,137).  The leaves partition idx in pre-order, so the concatenated
+    // leaf index list is idx itself and a leaf's offset into it is lo.
+    out.nodes.push_back(HostNode{box, 3, 0, lo, n});
+    out.total++;
   }
 };
 
@@ -165,10 +269,16 @@ HostBvh build_bvh(const rt_sphere* spheres, size_t n) {
     }
     b.idx[i] = i;
   }
-  b.out.nodes.reserve(2 * n + 1);
-  b.out.leaf_indices.reserve(n);
-  b.build(0, n, 1);
-  return std::move(b.out);
+  b.max_threads = host_threads();
+  b.grain = std::max(kParallelGrain, n / 64);
+  Subtree t;
+  b.build(0, n, 1, t);
+  HostBvh out;
+  out.nodes.reserve(t.total);
+  t.flatten_into(out.nodes);
+  out.leaf_indices = std::move(b.idx);
+  out.depth = t.depth;
+  return out;
 }
 
 namespace {

@@ -57,6 +57,12 @@ def test_host_bvh_equals_oracle_bvh(oracle):
     _same_tree(oracle, sp)
 
 
+def test_host_bvh_threaded_build_equals_oracle_bvh(oracle):
+    # large enough for the builder to bin with several threads and to build subtrees on their own threads
+    n, depth = _same_tree(oracle, rt.scene_field(3, 40000, 1.0 / 3.0, 1.0 / 3.0)[0])
+    assert n > 70000
+
+
 def test_host_bvh_edge_cases(oracle):
     sp = np.zeros(0, dtype=rt.SPHERE_DTYPE)
     boxes, kind, soc, leaf, depth = rt.host_bvh(sp)
