@@ -211,9 +211,9 @@ __device__ __forceinline__ float f32_above(double v) {  // smallest f32 >= v
 }
 // One box given as (lo, hi) pairs per axis: does the ray cross it within [tminf, tmaxf]?
 __device__ __forceinline__ bool box_test(const RayBox& q, f32x2 bx, f32x2 by, f32x2 bz, float tminf, float tmaxf) {
-  f32x2 tx = __builtin_elementwise_fma(bx, f32x2{q.rx, q.rx}, q.cx);
-  f32x2 ty = __builtin_elementwise_fma(by, f32x2{q.ry, q.ry}, q.cy);
-  f32x2 tz = __builtin_elementwise_fma(bz, f32x2{q.rz, q.rz}, q.cz);
+  f32x2 tx = f32x2{fmaf(bx.x, q.rx, q.cx.x), fmaf(bx.y, q.rx, q.cx.y)};
+  f32x2 ty = f32x2{fmaf(by.x, q.ry, q.cy.x), fmaf(by.y, q.ry, q.cy.y)};
+  f32x2 tz = f32x2{fmaf(bz.x, q.rz, q.cz.x), fmaf(bz.y, q.rz, q.cz.y)};
   float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tminf));
   float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tmaxf));
   return tn <= tf;
