@@ -286,43 +286,51 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
 
       bool finished = false;
       for (;;) {
-        // What does each lane want next?
-        const bool w_inner = !(tr.cur & kRefLeaf);
-        const uint32_t n_inner = count_lanes(w_inner);
-        int pick = BLK_INNER;
-        if (n_inner < P.inner_min) {
-          const uint32_t n_leaf = count_lanes((tr.cur & kRefLeaf) && tr.cur < kRefIdle);
-          const uint32_t n_shade = count_lanes(tr.cur == kRefDone);
-          const uint32_t n_camera = count_lanes(tr.cur == kRefCamera);
-          if ((n_inner | n_leaf | n_shade | n_camera) == 0u) {
-            finished = true;
-            break;
-          }
-          uint32_t most = n_inner;
-          if (n_leaf > most) {
-            most = n_leaf;
-            pick = BLK_LEAF;
-          }
-          if (n_shade > most) {
-            most = n_shade;
-            pick = BLK_SHADE;
-          }
-          if (n_camera > most) pick = BLK_CAMERA;
-        }
-        if (pick == BLK_INNER) {
+        // Inner-node rounds while enough lanes want them: the innermost loop, which only moves
+        // the cursor and the stack.
+        uint32_t n_inner = count_lanes(!(tr.cur & kRefLeaf));
+        while (n_inner >= P.inner_min) {
           RTA_T0()
-          if (w_inner) {
+          if (!(tr.cur & kRefLeaf)) {
             RTA_PROF(BLK_INNER)
             trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
             if (kProf) ++n_steps;
-            // Most lanes that took a step want another one: take it before counting again.
 #pragma unroll
-            for (int k = 1; k < kInnerSteps; ++k) {
+            for (int k = 1; k < kInnerSteps; ++k) {  // most lanes that took a step want another one
               if (!(tr.cur & kRefLeaf)) {
                 trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
                 if (kProf) ++n_steps;
               }
             }
+          }
+          RTA_T1(BLK_INNER)
+          n_inner = count_lanes(!(tr.cur & kRefLeaf));
+        }
+        // Too few: run the block most lanes are waiting for.
+        const uint32_t n_leaf = count_lanes((tr.cur & kRefLeaf) && tr.cur < kRefIdle);
+        const uint32_t n_shade = count_lanes(tr.cur == kRefDone);
+        const uint32_t n_camera = count_lanes(tr.cur == kRefCamera);
+        if ((n_inner | n_leaf | n_shade | n_camera) == 0u) {
+          finished = true;
+          break;
+        }
+        int pick = BLK_INNER;
+        uint32_t most = n_inner;
+        if (n_leaf > most) {
+          most = n_leaf;
+          pick = BLK_LEAF;
+        }
+        if (n_shade > most) {
+          most = n_shade;
+          pick = BLK_SHADE;
+        }
+        if (n_camera > most) pick = BLK_CAMERA;
+        if (pick == BLK_INNER) {
+          RTA_T0()
+          if (!(tr.cur & kRefLeaf)) {
+            RTA_PROF(BLK_INNER)
+            trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
+            if (kProf) ++n_steps;
           }
           RTA_T1(BLK_INNER)
         } else if (pick == BLK_LEAF) {
