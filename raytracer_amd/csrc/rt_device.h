@@ -179,10 +179,11 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 struct RayBox {
   float rx, ry, rz;  // reciprocal direction
-  f32x2 cx, cy, cz;  // (c_lo, c_hi) per axis
+  f32x2 cx, cy, cz;  // (c_lo, c_hi) per axis: constants for the box's low and high plane
+  f32x2 nx, ny, nz;  // (c_near, c_far) per axis: the same two constants by the order the ray meets the planes
 };
 
-__device__ __forceinline__ void ray_box_axis(double o, double d, float bound, float& rf, f32x2& c2) {
+__device__ __forceinline__ void ray_box_axis(double o, double d, float bound, float& rf, f32x2& c2, f32x2& s2) {
   float df = (float)d;
   float r = __builtin_amdgcn_rcpf(df);
   float of = (float)o;
@@ -193,12 +194,13 @@ __device__ __forceinline__ void ray_box_axis(double o, double d, float bound, fl
   bool neg = r < 0.0f;
   rf = ok ? r : 0.0f;
   c2 = ok ? (neg ? f32x2{cf, cn} : f32x2{cn, cf}) : f32x2{-__builtin_inff(), __builtin_inff()};
+  s2 = ok ? f32x2{cn, cf} : f32x2{-__builtin_inff(), __builtin_inff()};
 }
 __device__ __forceinline__ RayBox ray_box(D3 o, D3 d, float bound) {
   RayBox q;
-  ray_box_axis(o.x, d.x, bound, q.rx, q.cx);
-  ray_box_axis(o.y, d.y, bound, q.ry, q.cy);
-  ray_box_axis(o.z, d.z, bound, q.rz, q.cz);
+  ray_box_axis(o.x, d.x, bound, q.rx, q.cx, q.nx);
+  ray_box_axis(o.y, d.y, bound, q.ry, q.cy, q.ny);
+  ray_box_axis(o.z, d.z, bound, q.rz, q.cz, q.nz);
   return q;
 }
 __device__ __forceinline__ float f32_below(double v) {  // largest f32 <= v
@@ -218,6 +220,13 @@ __device__ __forceinline__ bool box_test(const RayBox& q, f32x2 bx, f32x2 by, f3
   float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tmaxf));
   return tn <= tf;
 }
+// One box given by the planes the ray meets first (nx, ny, nz) and last (fx, fy, fz) on each axis.
+__device__ __forceinline__ bool box_test_sorted(const RayBox& q, float nx, float ny, float nz, float fx, float fy, float fz, float tminf,
+                                                float tmaxf) {
+  float tn = fmaxf(fmaxf(fmaf(nx, q.rx, q.nx.x), fmaf(ny, q.ry, q.ny.x)), fmaxf(fmaf(nz, q.rz, q.nz.x), tminf));
+  float tf = fminf(fminf(fmaf(fx, q.rx, q.nx.y), fmaf(fy, q.ry, q.ny.y)), fminf(fmaf(fz, q.rz, q.nz.y), tmaxf));
+  return tn <= tf;
+}
 
 // ------------------------------------------------------------- traversal ----
 // Device tree: inner nodes only, 64 bytes each, holding the boxes of both
@@ -231,7 +240,11 @@ constexpr uint32_t kRefDone = 0xffffffffu;  // traversal finished / empty tree
 // Two more values the render kernel keeps in the same register to say what a lane wants next.
 constexpr uint32_t kRefCamera = 0xfffffffeu;  // start the next sample
 constexpr uint32_t kRefIdle = 0xfffffffdu;    // nothing left to do; every leaf ref is below this value
-constexpr uint32_t kLdsNodeQuads = 5;         // LDS stride of a node in 16-byte words (80 B: spreads nodes over banks)
+// A node staged in LDS is 7 quads (112 B): for each axis the four planes twice, ordered for rays
+// that travel up the axis, (lo0, lo1, hi0, hi1), and for rays that travel down it,
+// (hi0, hi1, lo0, lo1); then the references.  A lane reads the copy that matches its direction and
+// gets the planes it meets first in .xy and those it meets last in .zw, with no min/max per axis.
+constexpr uint32_t kLdsNodeQuads = 7;
 
 typedef __attribute__((address_space(3))) f32x4 lds_float4;
 typedef __attribute__((address_space(3))) f64x2 lds_double2;
@@ -251,24 +264,34 @@ struct TreeView {
   float bound;
 };
 
-// kAllLds: the whole tree and all spheres are in LDS, so no global path is compiled in.
-template <bool kAllLds>
-__device__ __forceinline__ void fetch_node(const TreeView& tv, uint32_t i, f32x4& q0, f32x4& q1, f32x4& q2, f32x4& q3) {
-  if (kAllLds || i < tv.n_lds) {
-    lds_float4* p = (lds_float4*)((__attribute__((address_space(3))) char*)tv.lnodes + __umul24(i, kLdsNodeQuads * 16u));  // full-rate 24-bit multiply
-    q0 = p[0];
-    q1 = p[1];
-    q2 = p[2];
-    q3 = p[3];
-  } else {
-    const f32x4* p = reinterpret_cast<const f32x4*>(tv.gnodes) + 4 * (size_t)i;
-    q0 = p[0];
-    q1 = p[1];
-    q2 = p[2];
-    q3 = p[3];
-  }
+// Writes node i (global layout q0..q3) into its LDS slot.
+__device__ __forceinline__ void stage_node(lds_float4* lnodes, uint32_t i, f32x4 q0, f32x4 q1, f32x4 q2, f32x4 q3) {
+  lds_float4* p = lnodes + kLdsNodeQuads * i;
+  p[0] = f32x4{q0.x, q0.z, q0.y, q0.w};
+  p[1] = f32x4{q0.y, q0.w, q0.x, q0.z};
+  p[2] = f32x4{q1.x, q1.z, q1.y, q1.w};
+  p[3] = f32x4{q1.y, q1.w, q1.x, q1.z};
+  p[4] = f32x4{q2.x, q2.z, q2.y, q2.w};
+  p[5] = f32x4{q2.y, q2.w, q2.x, q2.z};
+  p[6] = q3;
 }
-static_assert(kLdsNodeQuads == 5, "fetch_node computes 5*i");
+// Node i from LDS for a ray whose byte offsets into the node are off = (x, y, z copy to read).
+__device__ __forceinline__ void fetch_node_lds(const TreeView& tv, uint32_t i, uint32_t offx, uint32_t offy, uint32_t offz, f32x4& X, f32x4& Y,
+                                               f32x4& Z, f32x4& q3) {
+  typedef __attribute__((address_space(3))) char lds_char;
+  lds_char* base = (lds_char*)tv.lnodes;
+  X = *(lds_float4*)(base + __umul24(i, kLdsNodeQuads * 16u) + offx);  // 24-bit multiply-add, full rate
+  Y = *(lds_float4*)(base + __umul24(i, kLdsNodeQuads * 16u) + offy);
+  Z = *(lds_float4*)(base + __umul24(i, kLdsNodeQuads * 16u) + offz);
+  q3 = *(lds_float4*)(base + __umul24(i, kLdsNodeQuads * 16u) + 96u);
+}
+__device__ __forceinline__ void fetch_node_global(const TreeView& tv, uint32_t i, f32x4& q0, f32x4& q1, f32x4& q2, f32x4& q3) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(tv.gnodes) + 4 * (size_t)i;
+  q0 = p[0];
+  q1 = p[1];
+  q2 = p[2];
+  q3 = p[3];
+}
 
 template <bool kAllLds>
 __device__ __forceinline__ void fetch_sphere(const TreeView& tv, uint32_t slot, f64x2& s0, f64x2& s1) {
@@ -299,6 +322,7 @@ struct Trav {
   double t_best;
   float tmaxf;
   uint32_t sgn;  // bit a set: direction negative on axis a
+  uint32_t offx, offy, offz;  // byte offset, inside a node staged in LDS, of the copy of each axis to read
   uint32_t cur, sp;
   uint32_t tos;  // the top of the stack lives here; `sp` entries below it are in LDS
   int best;
@@ -311,6 +335,10 @@ __device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D
   tr.t_best = t_max;
   tr.tmaxf = (t_max < 3.0e38) ? f32_above(t_max) : __builtin_inff();
   tr.sgn = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
+  // The copy must match the sign the node test sees, which is that of the f32 reciprocal.
+  tr.offx = tr.q.rx < 0.0f ? 16u : 0u;
+  tr.offy = tr.q.ry < 0.0f ? 48u : 32u;
+  tr.offz = tr.q.rz < 0.0f ? 80u : 64u;
   tr.cur = tv.root;
   tr.sp = 0;
   tr.tos = kRefDone;  // popping the bottom entry ends the traversal
@@ -336,10 +364,19 @@ __device__ __forceinline__ void trav_push(Trav& tr, lds_u32* stack, uint32_t str
 // One inner node: test both children, descend into the first one hit.
 template <bool kAllLds>
 __device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, lds_u32* stack, uint32_t stride, float tminf) {
-  f32x4 q0, q1, q2, q3;
-  fetch_node<kAllLds>(tv, tr.cur, q0, q1, q2, q3);
-  const bool h0 = box_test(tr.q, f32x2{q0.x, q0.y}, f32x2{q1.x, q1.y}, f32x2{q2.x, q2.y}, tminf, tr.tmaxf);
-  const bool h1 = box_test(tr.q, f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, tminf, tr.tmaxf);
+  f32x4 q3;
+  bool h0, h1;
+  if (kAllLds || tr.cur < tv.n_lds) {
+    f32x4 X, Y, Z;
+    fetch_node_lds(tv, tr.cur, tr.offx, tr.offy, tr.offz, X, Y, Z, q3);
+    h0 = box_test_sorted(tr.q, X.x, Y.x, Z.x, X.z, Y.z, Z.z, tminf, tr.tmaxf);
+    h1 = box_test_sorted(tr.q, X.y, Y.y, Z.y, X.w, Y.w, Z.w, tminf, tr.tmaxf);
+  } else {
+    f32x4 q0, q1, q2;
+    fetch_node_global(tv, tr.cur, q0, q1, q2, q3);
+    h0 = box_test(tr.q, f32x2{q0.x, q0.y}, f32x2{q1.x, q1.y}, f32x2{q2.x, q2.y}, tminf, tr.tmaxf);
+    h1 = box_test(tr.q, f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, tminf, tr.tmaxf);
+  }
   const uint32_t ref0 = __float_as_uint(q3.x), ref1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
   const bool swap = ((tr.sgn >> axis) & 1u) != 0u;
   // Selects instead of a three-way branch: only the push and the pop are predicated.

@@ -29,7 +29,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
     const double* src = k < 3 ? cam->center : k < 6 ? cam->pixel00 : k < 9 ? cam->du : k < 12 ? cam->dv : k < 15 ? cam->disk_u : cam->disk_v;
     lcam[k] = src[k % 3];
   }
-  for (uint32_t i = threadIdx.x; i < 4 * sc.n_nodes_lds; i += wg) lnodes[(i >> 2) * kLdsNodeQuads + (i & 3u)] = gn[i];
+  for (uint32_t i = threadIdx.x; i < sc.n_nodes_lds; i += wg) stage_node(lnodes, i, gn[4 * i], gn[4 * i + 1], gn[4 * i + 2], gn[4 * i + 3]);
   for (uint32_t i = threadIdx.x; i < 2 * sc.n_spheres_lds; i += wg) lsph[i] = gs[i];
   for (uint32_t i = threadIdx.x; i < sc.n_aux_lds; i += wg) laux[i] = ga[i];
   for (uint32_t i = threadIdx.x; i < 2 * sc.n_materials_lds; i += wg) lmat[i] = gm[i];
