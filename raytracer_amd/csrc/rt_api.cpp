@@ -61,6 +61,8 @@ struct DeviceGuard {  // makes the scene's device current for the duration of a 
 
 // Lanes (of 64) that must want the inner-node block for a wave to run it without looking at the other blocks.
 uint32_t g_inner_min = 16;
+// Samples of one pixel that make a unit of work (the sample range is cut into chunks of about this size).
+uint32_t g_chunk_spp = 64;
 
 }  // namespace
 
@@ -432,16 +434,25 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
   if (stats) std::memset(stats, 0, sizeof(*stats));
   const uint32_t tw = r.x1 - r.x0, th = r.y1 - r.y0, spp = spp_end - spp_begin;
   if (tw == 0 || th == 0 || spp == 0) return RT_OK;
+  if (P.cam.max_depth == 0) {  // every sample is black (src/camera.rs:99-101): nothing to add to the frame
+    if (stats) stats->samples = (uint64_t)tw * th * spp;
+    return RT_OK;
+  }
 
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard g(sc->device);
   RT_HIP(g.status);
 
-  // Enough work items to fill the chip: split the sample range into chunks
-  // when the tile has few pixels.  The count depends on the request only.
+  // The sample range is cut into chunks: a unit of work is one pixel's samples of one chunk, and
+  // the lanes of a wave share out the units of one 8x8 tile, so a lane with a cheap pixel takes
+  // more of them.  Enough chunks to keep lanes busy (about g_chunk_spp samples each, at most 16),
+  // more when the rectangle has few pixels, fewer when the partial sums would not fit in 4 GB.
+  // The count depends on the request only.
   const uint64_t kTargetLanes = 1u << 21;
   uint64_t pixels = (uint64_t)tw * th;
-  uint32_t n_chunks = (uint32_t)std::min<uint64_t>(spp, std::max<uint64_t>(1, (kTargetLanes + pixels - 1) / pixels));
+  uint64_t want = std::max<uint64_t>(std::min<uint64_t>(16, spp / std::max<uint32_t>(1, g_chunk_spp)), (kTargetLanes + pixels - 1) / pixels);
+  want = std::min<uint64_t>(want, std::max<uint64_t>(1, (4ull << 30) / (pixels * 24)));
+  uint32_t n_chunks = (uint32_t)std::min<uint64_t>(spp, std::max<uint64_t>(1, want));
   uint32_t chunk_spp = (spp + n_chunks - 1) / n_chunks;
   n_chunks = (spp + chunk_spp - 1) / chunk_spp;
 
@@ -459,8 +470,16 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
   P.seed_lo = (uint32_t)seed;
   P.seed_hi = (uint32_t)(seed >> 32);
   uint64_t n_items = (uint64_t)P.n_tiles * n_chunks;
-  if (n_items >= 0xffffffffull) return fail(RT_ERR_LIMIT, "rt_render: too many work items; render a smaller tile or sample range");
-  P.n_items = (uint32_t)n_items;
+  // the unit counter is read as 32 bits and every lane overshoots it by one at the end
+  if (n_items * 64 >= 0xfff00000ull) return fail(RT_ERR_LIMIT, "rt_render: too many work units; render a smaller tile or sample range");
+  if (P.cam.width > 0xffffu || P.cam.height > 0xffffu) return fail(RT_ERR_LIMIT, "rt_render: images larger than 65535 pixels on a side are not supported");
+  P.n_units = (uint32_t)(n_items * 64);
+  // A wave takes some chunks of one tile at a time: all of them when there are many tiles per wave,
+  // fewer when there are not, so that every wave gets about 16 batches.
+  const uint64_t n_waves = (uint64_t)sc->num_cus * (kWorkgroup / 64);
+  P.batch_chunks = (uint32_t)std::min<uint64_t>(n_chunks, std::max<uint64_t>(1, n_items / (16 * n_waves)));
+  P.batches_per_tile = (n_chunks + P.batch_chunks - 1) / P.batch_chunks;
+  P.n_batches = P.n_tiles * P.batches_per_tile;
   P.direct = n_chunks == 1 ? 1u : 0u;
   P.inner_min = g_inner_min;
   if (const char* env = std::getenv("RT_INNER_MIN")) P.inner_min = (uint32_t)std::atoi(env);
@@ -554,6 +573,11 @@ int rt_debug_set(const char* name, double value) {
   if (!name) return fail(RT_ERR_INVALID, "rt_debug_set: name is null");
   if (std::strcmp(name, "inner_min") == 0) {
     g_inner_min = (uint32_t)value;
+    return RT_OK;
+  }
+  if (std::strcmp(name, "chunk_spp") == 0) {
+    if (!(value >= 1.0 && value <= 1e9)) return fail(RT_ERR_INVALID, "rt_debug_set: chunk_spp must be in 1 .. 1e9");
+    g_chunk_spp = (uint32_t)value;
     return RT_OK;
   }
   return fail(RT_ERR_INVALID, std::string("rt_debug_set: unknown tunable ") + name);

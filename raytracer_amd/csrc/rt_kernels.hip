@@ -158,9 +158,9 @@ __global__ __launch_bounds__(256) void primary_rays_kernel(CameraDev cam, uint32
 // Camera::ray_colour (src/camera.rs:98-112) unrolled into a loop.
 //
 // Persistent workgroups, one per CU: each stages the scene in LDS once, then
-// its waves pull work items (an 8x8 pixel tile x a chunk of the sample range)
-// from a global counter.  A lane owns one pixel of the tile and walks through
-// its samples in index order, so the sums do not depend on scheduling.
+// its lanes pull units of work (a pixel x a chunk of the sample range) from a
+// global counter, 8x8 pixel tiles in order.  One lane walks through a unit's
+// samples in index order, so the sums do not depend on scheduling.
 //
 // Every lane is a small state machine that wants exactly one of four code
 // blocks next: CAMERA (start the next sample), INNER (one inner BVH node:
@@ -207,73 +207,135 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
   // The lane's stack column is recomputed where it is used (one add), not kept in a register.
 #define RTA_STACK (im.stack_base + threadIdx.x)
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t tile_w = P.x1 - P.x0;
   const double t_min = 1e-3;  // src/camera.rs:102
   const float tminf = f32_below(t_min);
+  constexpr uint32_t kNoUnit = 0xffffffffu;
 
+  // A unit of work is one pixel's samples of one chunk of the sample range.  A wave takes a batch
+  // (some or all chunks of one 8x8 tile) at a time from the global counter and its lanes share out
+  // the batch's units (chunk by chunk, 64 pixels each) as they become free, so a lane whose pixel is cheap takes more units
+  // instead of idling, and all lanes of a wave look at the same part of the scene.  The samples
+  // of a unit are summed by one lane in index order and the chunks of a pixel are added in chunk
+  // order afterwards, so the sums do not depend on which lane gets which unit or when.
+  uint32_t unit = kNoUnit;      // the chunk index of the lane's unit, or kNoUnit
+  uint32_t pij = 0;             // the unit's pixel: i | j << 16
+  uint32_t s = 0, s_last = 0;   // next sample and end of the unit's sample range (s == s_last: unit finished)
+#define RTA_I (pij & 0xffffu)
+#define RTA_J (pij >> 16)
+  uint32_t n_rays = 0, n_samples = 0, n_steps = 0, n_tests = 0;  // the last two are only kept by the profiling variant
+  uint32_t prof_runs[4] = {0, 0, 0, 0}, prof_lanes[4] = {0, 0, 0, 0};
+  unsigned long long prof_cycles[5] = {0, 0, 0, 0, 0};  // per block, and [4] = the whole kernel
+  const unsigned long long kernel_t0 = kProf ? __builtin_amdgcn_s_memtime() : 0ull;
+  D3 acc = d3(0.0, 0.0, 0.0), thr = d3(1.0, 1.0, 1.0);
+  uint32_t depth_left = 0;
+  Trav tr;
+  // What a lane wants next is encoded in tr.cur: an inner node, a leaf, kRefDone (shade),
+  // kRefCamera (start the next sample, fetching a unit first if need be) or kRefIdle (no units left).
+  tr.cur = kRefCamera;
+
+  // Where a finished unit's sum goes: added to the image, or stored in the unit's slot of the partial-sum buffer.
+  auto flush = [&]() {
+    const uint32_t i = RTA_I, j = RTA_J;
+    if (P.direct) {
+      double* px = P.out + 3 * ((size_t)j * P.cam.width + i);
+      px[0] += acc.x;
+      px[1] += acc.y;
+      px[2] += acc.z;
+    } else {
+      const uint32_t tile_w = P.x1 - P.x0;
+      double* px = P.out + 3 * ((size_t)unit * tile_w * (P.y1 - P.y0) + (size_t)(j - P.y0) * tile_w + (i - P.x0));
+      px[0] = acc.x;
+      px[1] = acc.y;
+      px[2] = acc.z;
+    }
+  };
+
+  // The wave alternates between a cold part (one SHADE or CAMERA block, which rewrite the whole
+  // lane state) and a hot loop that only walks the tree (INNER and LEAF blocks touch the cursor,
+  // the stack and the closest hit, nothing else), so the hot loop carries few live values around.
+  // The wave's current batch: units [wave_next, wave_end) are still to be handed out; wave_base is the
+  // first unit of the batch's tile and wave_origin the tile's top left pixel, i | j << 16.
+  uint32_t wave_next = 0, wave_end = 0, wave_base = 0, wave_origin = 0;
+  int block = BLK_CAMERA;
   for (;;) {
-    uint32_t item = 0;
-    if (lane == 0) item = (uint32_t)atomicAdd(&P.counters[0], 1ull);
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= P.n_items) break;
-    const uint32_t tile = item / P.n_chunks, chunk = item - tile * P.n_chunks;
-    const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-    const uint32_t i0 = P.x0 + tx * 8u, j0 = P.y0 + ty * 8u;  // wave-uniform tile origin; a lane's pixel is (i0 + lane%8, j0 + lane/8)
-#define RTA_I (i0 + (threadIdx.x & 7u))
-#define RTA_J (j0 + ((threadIdx.x >> 3) & 7u))
-    const bool valid = RTA_I < P.x1 && RTA_J < P.y1;
-    const uint32_t s_first = P.spp_begin + chunk * P.chunk_spp;
-    const uint32_t s_last = min(s_first + P.chunk_spp, P.spp_end);
-
-    uint32_t s = s_first;
-    uint32_t n_rays = 0, n_steps = 0, n_tests = 0;  // the last two are only kept by the profiling variant
-    uint32_t prof_runs[4] = {0, 0, 0, 0}, prof_lanes[4] = {0, 0, 0, 0};
-    unsigned long long prof_cycles[5] = {0, 0, 0, 0, 0};  // per block, and [4] = the whole item
-    const unsigned long long item_t0 = kProf ? __builtin_amdgcn_s_memtime() : 0ull;
-    D3 acc = d3(0.0, 0.0, 0.0), thr = d3(1.0, 1.0, 1.0);
-    uint32_t depth_left = 0;
-    Trav tr;
-    // What a lane wants next is encoded in tr.cur: an inner node, a leaf, kRefDone (shade),
-    // kRefCamera (start the next sample) or kRefIdle (all samples finished).
-    tr.cur = (valid && s < s_last && P.cam.max_depth != 0) ? kRefCamera : kRefIdle;  // max_depth 0: every sample is black (src/camera.rs:99-101)
-
-    // The wave alternates between a cold part (one SHADE or CAMERA block, which rewrite the whole
-    // lane state) and a hot loop that only walks the tree (INNER and LEAF blocks touch the cursor,
-    // the stack and the closest hit, nothing else), so the hot loop carries few live values around.
-    int block = BLK_CAMERA;
-    for (;;) {
-      {
-        RTA_T0()
-        if (block == BLK_SHADE) {
-          if (tr.cur == kRefDone) {
-            RTA_PROF(BLK_SHADE)
-            ++n_rays;
-            bool ended = true;
-            if (tr.best < 0) {  // sky, src/camera.rs:103-107
-              double a = (tr.d.y + 1.0) / 2.0;
-              D3 sky = d3((1.0 - a) + a * 0.5, (1.0 - a) + a * 0.7, (1.0 - a) + a * 1.0);
-              acc = acc + thr * sky;
-            } else {
-              const Hit h = make_hit<kAllLds>(tv, tr.best, tr.o, tr.d, tr.t_best);
-              double u0, u1;
-              philox_pair(P.seed_lo, P.seed_hi, RTA_J * P.cam.width + RTA_I, s, P.cam.max_depth - depth_left, DOM_SCATTER, u0, u1);
-              D3 att, nd;
-              if (scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd)) {  // None = absorbed, src/camera.rs:108-110
-                thr = thr * att;
-                if (--depth_left != 0) {  // depth exhausted: the path contributes nothing (src/camera.rs:99-101)
-                  trav_begin(tr, tv, h.p, nd, __builtin_inf());  // HitRecord::ray, src/hit.rs:29-31
-                  ended = false;
-                }
+    {
+      RTA_T0()
+      if (block == BLK_SHADE) {
+        if (tr.cur == kRefDone) {
+          RTA_PROF(BLK_SHADE)
+          ++n_rays;
+          bool ended = true;
+          if (tr.best < 0) {  // sky, src/camera.rs:103-107
+            double a = (tr.d.y + 1.0) / 2.0;
+            D3 sky = d3((1.0 - a) + a * 0.5, (1.0 - a) + a * 0.7, (1.0 - a) + a * 1.0);
+            acc = acc + thr * sky;
+          } else {
+            const Hit h = make_hit<kAllLds>(tv, tr.best, tr.o, tr.d, tr.t_best);
+            double u0, u1;
+            philox_pair(P.seed_lo, P.seed_hi, RTA_J * P.cam.width + RTA_I, s, P.cam.max_depth - depth_left, DOM_SCATTER, u0, u1);
+            D3 att, nd;
+            if (scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd)) {  // None = absorbed, src/camera.rs:108-110
+              thr = thr * att;
+              if (--depth_left != 0) {  // depth exhausted: the path contributes nothing (src/camera.rs:99-101)
+                trav_begin(tr, tv, h.p, nd, __builtin_inf());  // HitRecord::ray, src/hit.rs:29-31
+                ended = false;
               }
             }
-            if (ended) {
-              ++s;
-              tr.cur = (s < s_last) ? kRefCamera : kRefIdle;
+          }
+          if (ended) {
+            ++s;
+            tr.cur = kRefCamera;
+          }
+        }
+      } else {
+        // The wave hands out the units of its current batch in order; when they run out it takes
+        // the next batch from the global counter.  (Wave-uniform bookkeeping, done by all lanes.)
+        const uint32_t n_need = count_lanes(tr.cur == kRefCamera && s >= s_last);
+        const uint32_t old_next = wave_next, old_avail = wave_end - wave_next, old_base = wave_base, old_origin = wave_origin;
+        uint32_t new_first = 0;
+        if (n_need > old_avail) {
+          uint32_t b = 0;
+          if (lane == 0) b = (uint32_t)min(atomicAdd(&P.counters[0], 1ull), (unsigned long long)P.n_batches);
+          b = __builtin_amdgcn_readfirstlane(b);  // b == n_batches: nothing left (tile n_tiles starts at n_units)
+          const uint32_t t = b / P.batches_per_tile, c0 = (b - t * P.batches_per_tile) * P.batch_chunks;
+          const uint32_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+          wave_base = t * P.n_chunks * 64u;
+          wave_origin = (P.x0 + tx * 8u) | ((P.y0 + ty * 8u) << 16);
+          const uint32_t first = min(wave_base + c0 * 64u, P.n_units);
+          wave_end = min(wave_base + min(c0 + P.batch_chunks, P.n_chunks) * 64u, P.n_units);
+          wave_next = min(first + (n_need - old_avail), wave_end);
+          new_first = first;
+        } else {
+          wave_next += n_need;
+        }
+        if (tr.cur == kRefCamera) {
+          RTA_PROF(BLK_CAMERA)
+          if (s >= s_last) {  // the unit is finished (or there was none yet): hand in its sum and take the next one
+            if (unit != kNoUnit) flush();
+            const unsigned long long need = __ballot(1);
+            const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            const bool from_old = k < old_avail;
+            const uint32_t rel = from_old ? old_next + k - old_base : new_first + (k - old_avail) - wave_base;  // unit within its tile
+            if (from_old || wave_base + rel < wave_end) {
+              const uint32_t origin = from_old ? old_origin : wave_origin, chunk = rel >> 6;
+              const uint32_t i = (origin & 0xffffu) + (rel & 7u), j = (origin >> 16) + ((rel >> 3) & 7u);
+              unit = chunk;
+              pij = i | (j << 16);
+              acc = d3(0.0, 0.0, 0.0);
+              if (i < P.x1 && j < P.y1) {
+                s = P.spp_begin + chunk * P.chunk_spp;
+                s_last = min(s + P.chunk_spp, P.spp_end);
+                n_samples += s_last - s;
+              } else {  // the tile sticks out of the rectangle: an empty unit
+                unit = kNoUnit;
+                s = s_last = 0;
+              }
+            } else {
+              unit = kNoUnit;
+              tr.cur = kRefIdle;
             }
           }
-        } else {
-          if (tr.cur == kRefCamera) {  // Camera::get_ray, src/camera.rs:147-148
-            RTA_PROF(BLK_CAMERA)
+          if (tr.cur == kRefCamera && s < s_last) {  // Camera::get_ray, src/camera.rs:147-148
             D3 o, d;
             camera_ray(im.cam, P.cam.width, P.cam.defocus != 0, P.seed_lo, P.seed_hi, RTA_I, RTA_J, s, o, d);
             thr = d3(1.0, 1.0, 1.0);
@@ -281,120 +343,105 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
             trav_begin(tr, tv, o, d, __builtin_inf());
           }
         }
-        RTA_T1(block)
       }
+      RTA_T1(block)
+    }
 
-      bool finished = false;
-      for (;;) {
-        // Inner-node rounds while enough lanes want them: the innermost loop, which only moves
-        // the cursor and the stack.
-        uint32_t n_inner = count_lanes(!(tr.cur & kRefLeaf));
-        while (n_inner >= P.inner_min) {
-          RTA_T0()
-          if (!(tr.cur & kRefLeaf)) {
-            RTA_PROF(BLK_INNER)
-            trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
-            if (kProf) ++n_steps;
+    bool finished = false;
+    for (;;) {
+      // Inner-node rounds while enough lanes want them: the innermost loop, which only moves
+      // the cursor and the stack.
+      uint32_t n_inner = count_lanes(!(tr.cur & kRefLeaf));
+      while (n_inner >= P.inner_min) {
+        RTA_T0()
+        if (!(tr.cur & kRefLeaf)) {
+          RTA_PROF(BLK_INNER)
+          trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
+          if (kProf) ++n_steps;
 #pragma unroll
-            for (int k = 1; k < kInnerSteps; ++k) {  // most lanes that took a step want another one
-              if (!(tr.cur & kRefLeaf)) {
-                trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
-                if (kProf) ++n_steps;
-              }
+          for (int k = 1; k < kInnerSteps; ++k) {  // most lanes that took a step want another one
+            if (!(tr.cur & kRefLeaf)) {
+              trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
+              if (kProf) ++n_steps;
             }
           }
-          RTA_T1(BLK_INNER)
-          n_inner = count_lanes(!(tr.cur & kRefLeaf));
         }
-        // Too few: run the block most lanes are waiting for.
-        const uint32_t n_leaf = count_lanes((tr.cur & kRefLeaf) && tr.cur < kRefIdle);
-        const uint32_t n_shade = count_lanes(tr.cur == kRefDone);
-        const uint32_t n_camera = count_lanes(tr.cur == kRefCamera);
-        if ((n_inner | n_leaf | n_shade | n_camera) == 0u) {
-          finished = true;
-          break;
-        }
-        int pick = BLK_INNER;
-        uint32_t most = n_inner;
-        if (n_leaf > most) {
-          most = n_leaf;
-          pick = BLK_LEAF;
-        }
-        if (n_shade > most) {
-          most = n_shade;
-          pick = BLK_SHADE;
-        }
-        if (n_camera > most) pick = BLK_CAMERA;
-        if (pick == BLK_INNER) {
-          RTA_T0()
-          if (!(tr.cur & kRefLeaf)) {
-            RTA_PROF(BLK_INNER)
-            trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
-            if (kProf) ++n_steps;
-          }
-          RTA_T1(BLK_INNER)
-        } else if (pick == BLK_LEAF) {
-          RTA_T0()
-          if ((tr.cur & kRefLeaf) && tr.cur < kRefIdle) {
-            RTA_PROF(BLK_LEAF)
-            uint32_t tests = 0;
-            trav_leaf_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, t_min, tests);
-            if (kProf) n_tests += tests;
-          }
-          RTA_T1(BLK_LEAF)
-        } else {
-          block = pick;
-          break;
-        }
+        RTA_T1(BLK_INNER)
+        n_inner = count_lanes(!(tr.cur & kRefLeaf));
       }
-      if (finished) break;
-    }
-    if (kProf) prof_cycles[4] = __builtin_amdgcn_s_memtime() - item_t0;
-
-    if (valid) {
-      const uint32_t i = RTA_I, j = RTA_J;
-      if (P.direct) {
-        double* px = P.out + 3 * ((size_t)j * P.cam.width + i);
-        px[0] += acc.x;
-        px[1] += acc.y;
-        px[2] += acc.z;
+      // Too few: run the block most lanes are waiting for.
+      const uint32_t n_leaf = count_lanes((tr.cur & kRefLeaf) && tr.cur < kRefIdle);
+      const uint32_t n_shade = count_lanes(tr.cur == kRefDone);
+      const uint32_t n_camera = count_lanes(tr.cur == kRefCamera);
+      if ((n_inner | n_leaf | n_shade | n_camera) == 0u) {
+        finished = true;
+        break;
+      }
+      int pick = BLK_INNER;
+      uint32_t most = n_inner;
+      if (n_leaf > most) {
+        most = n_leaf;
+        pick = BLK_LEAF;
+      }
+      if (n_shade > most) {
+        most = n_shade;
+        pick = BLK_SHADE;
+      }
+      if (n_camera > most) pick = BLK_CAMERA;
+      if (pick == BLK_INNER) {
+        RTA_T0()
+        if (!(tr.cur & kRefLeaf)) {
+          RTA_PROF(BLK_INNER)
+          trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
+          if (kProf) ++n_steps;
+        }
+        RTA_T1(BLK_INNER)
+      } else if (pick == BLK_LEAF) {
+        RTA_T0()
+        if ((tr.cur & kRefLeaf) && tr.cur < kRefIdle) {
+          RTA_PROF(BLK_LEAF)
+          uint32_t tests = 0;
+          trav_leaf_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, t_min, tests);
+          if (kProf) n_tests += tests;
+        }
+        RTA_T1(BLK_LEAF)
       } else {
-        double* px = P.out + 3 * ((size_t)chunk * tile_w * (P.y1 - P.y0) + (size_t)(j - P.y0) * tile_w + (i - P.x0));
-        px[0] = acc.x;
-        px[1] = acc.y;
-        px[2] = acc.z;
+        block = pick;
+        break;
       }
     }
-    // one counter update per wave and item
-    const uint32_t n_samples = valid ? s_last - s_first : 0u;  // every sample of the chunk was started (or is black at max_depth 0)
-    unsigned long long c_rays = n_rays, c_samples = n_samples, c_steps = n_steps, c_tests = n_tests;
-    for (int off = 32; off > 0; off >>= 1) {
-      c_rays += __shfl_down(c_rays, off);
-      c_samples += __shfl_down(c_samples, off);
-      c_steps += __shfl_down(c_steps, off);
-      c_tests += __shfl_down(c_tests, off);
-    }
-    if (lane == 0) {
-      atomicAdd(&P.counters[1], c_rays);
-      atomicAdd(&P.counters[2], c_samples);
-      atomicAdd(&P.counters[3], c_steps);
-      atomicAdd(&P.counters[4], c_tests);
-    }
-    if (kProf) {  // each run was counted by one elected lane: sum over the wave
-      for (int k = 0; k < 4; ++k) {
-        unsigned long long r = prof_runs[k], l = prof_lanes[k];
-        for (int off = 32; off > 0; off >>= 1) {
-          r += __shfl_down(r, off);
-          l += __shfl_down(l, off);
-        }
-        if (lane == 0) {
-          atomicAdd(&P.counters[5 + 2 * k], r);
-          atomicAdd(&P.counters[6 + 2 * k], l);
-        }
+    if (finished) break;
+  }
+  if (kProf) prof_cycles[4] = __builtin_amdgcn_s_memtime() - kernel_t0;
+
+  // one counter update per wave
+  unsigned long long c_rays = n_rays, c_samples = n_samples, c_steps = n_steps, c_tests = n_tests;
+  for (int off = 32; off > 0; off >>= 1) {
+    c_rays += __shfl_down(c_rays, off);
+    c_samples += __shfl_down(c_samples, off);
+    c_steps += __shfl_down(c_steps, off);
+    c_tests += __shfl_down(c_tests, off);
+  }
+  if (lane == 0) {
+    atomicAdd(&P.counters[1], c_rays);
+    atomicAdd(&P.counters[2], c_samples);
+    atomicAdd(&P.counters[3], c_steps);
+    atomicAdd(&P.counters[4], c_tests);
+  }
+  if (kProf) {  // each run was counted by one elected lane: sum over the wave
+    for (int k = 0; k < 4; ++k) {
+      unsigned long long r = prof_runs[k], l = prof_lanes[k];
+      for (int off = 32; off > 0; off >>= 1) {
+        r += __shfl_down(r, off);
+        l += __shfl_down(l, off);
       }
-      if (lane == 0)
-        for (int k = 0; k < 5; ++k) atomicAdd(&P.counters[13 + k], prof_cycles[k]);
+      if (lane == 0) {
+        atomicAdd(&P.counters[5 + 2 * k], r);
+        atomicAdd(&P.counters[6 + 2 * k], l);
+      }
     }
+    if (lane == 0)
+      for (int k = 0; k < 5; ++k) atomicAdd(&P.counters[13 + k], prof_cycles[k]);
   }
 }
 

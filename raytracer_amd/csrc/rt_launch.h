@@ -45,14 +45,15 @@ struct RenderParams {
   uint32_t n_chunks, chunk_spp;
   uint32_t spp_begin, spp_end;
   uint32_t seed_lo, seed_hi;
-  uint32_t n_items;
+  uint32_t n_units;    // 64 x tiles x chunks
+  uint32_t batch_chunks, batches_per_tile, n_batches;  // a wave takes batch_chunks chunks of one tile at a time from the global counter
   uint32_t direct;     // 1: out is the image and is added to; 0: out is the partial-sum buffer and is overwritten
   uint32_t inner_min;  // a wave runs the inner-node block while at least this many of its lanes want it
   double* out;
   unsigned long long* counters;  // see kRenderCounters
 };
 
-// counters: [0] next work item, [1] rays, [2] samples, [3] node steps, [4] sphere tests;
+// counters: [0] next batch, [1] rays, [2] samples, [3] node steps, [4] sphere tests;
 // profiling variant only: [5+2k] runs and [6+2k] active lanes of block k, [13+k] shader-clock
 // cycles of block k, [17] cycles of whole work items.
 constexpr int kRenderCounters = 18;
