@@ -108,8 +108,10 @@ typedef struct rt_scene_info {
   uint32_t spheres_in_lds;  /* bit 0: sphere records staged in LDS too; bit 1: their shading data; bit 2: the materials */
   uint32_t device;          /* HIP device ordinal the scene lives on */
   uint64_t device_bytes;    /* HBM held by the scene */
-  double build_ms;          /* host BVH build + flatten */
+  double build_ms;          /* BVH build (+ flatten on the host path) */
   uint64_t lds_bytes;       /* LDS each workgroup of the tree-walking kernels uses for this scene */
+  uint32_t builder;         /* RT_BUILD_* that made the tree (the device builder falls back to the host for very deep trees) */
+  uint32_t reserved;
 } rt_scene_info;
 
 typedef struct rt_scene rt_scene;
@@ -127,6 +129,16 @@ int rt_camera_derive(const rt_config* cfg, rt_camera* out);
  * spatial splits): copies the inputs, builds the binned-SAH tree on the host,
  * flattens it and uploads it to the current HIP device. */
 int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_material* materials, size_t n_materials, rt_scene** out);
+
+/* rt_scene_create with a choice of tree builder.  RT_BUILD_HOST_SAH is the
+ * reference's binned-SAH tree, built by host threads.  RT_BUILD_DEVICE_LBVH
+ * builds a linear BVH (Morton order) on the GPU in milliseconds: a different
+ * tree over the same spheres, so closest hits are the same (exact ties between
+ * overlapping spheres aside) while traversal takes somewhat more steps; for
+ * scenes whose host build would cost more than their render. */
+enum { RT_BUILD_HOST_SAH = 0, RT_BUILD_DEVICE_LBVH = 1 };
+int rt_scene_create_ex(const rt_sphere* spheres, size_t n_spheres, const rt_material* materials, size_t n_materials, uint32_t builder,
+                       rt_scene** out);
 int rt_scene_destroy(rt_scene* scene);
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 

@@ -55,10 +55,13 @@ SCENE_INFO_DTYPE = np.dtype(
         ("device_bytes", "<u8"),
         ("build_ms", "<f8"),
         ("lds_bytes", "<u8"),
+        ("builder", "<u4"),
+        ("reserved", "<u4"),
     ]
 )
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
+BUILD_HOST_SAH, BUILD_DEVICE_LBVH = 0, 1
 
 # Every symbol include/rt.h declares.
 EXPORTS = [
@@ -66,6 +69,7 @@ EXPORTS = [
     "rt_config_default",
     "rt_camera_derive",
     "rt_scene_create",
+    "rt_scene_create_ex",
     "rt_scene_destroy",
     "rt_scene_get_info",
     "rt_bvh_build",

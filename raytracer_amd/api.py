@@ -166,9 +166,10 @@ def flatten(objects):
 class BVH:
     """`BVH::new(objects)` (src/bvh.rs:44-48) on the current HIP device.
 
-    `objects` is a list of Sphere, or a pair (sphere records, material records)."""
+    `objects` is a list of Sphere, or a pair (sphere records, material records).  builder: BUILD_HOST_SAH (the
+    reference's tree) or BUILD_DEVICE_LBVH (built on the GPU; same hits, a different tree)."""
 
-    def __init__(self, objects, materials=None):
+    def __init__(self, objects, materials=None, builder=0):
         if materials is None and not isinstance(objects, np.ndarray):
             spheres, materials = flatten(list(objects))
         else:
@@ -176,7 +177,8 @@ class BVH:
             materials = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
         self.spheres, self.materials = spheres, materials
         h = C.c_void_p()
-        check(_lib.lib().rt_scene_create(ptr(spheres), C.c_size_t(len(spheres)), ptr(materials), C.c_size_t(len(materials)), C.byref(h)))
+        check(_lib.lib().rt_scene_create_ex(ptr(spheres), C.c_size_t(len(spheres)), ptr(materials), C.c_size_t(len(materials)),
+                                            C.c_uint32(builder), C.byref(h)))
         self._h = h
 
     new = classmethod(lambda cls, objects: cls(objects))

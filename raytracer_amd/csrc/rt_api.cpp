@@ -15,6 +15,7 @@
 #include "bvh_builder.h"
 #include "rt.h"
 #include "rt_host.h"
+#include "rt_build.h"
 #include "rt_launch.h"
 
 using namespace rta;
@@ -130,7 +131,12 @@ int rt_camera_derive(const rt_config* cfg, rt_camera* out) {
 }
 
 int rt_scene_create(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, rt_scene** out) {
+  return rt_scene_create_ex(spheres, n, materials, nm, RT_BUILD_HOST_SAH, out);
+}
+
+int rt_scene_create_ex(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, uint32_t builder, rt_scene** out) {
   if (!out) return fail(RT_ERR_INVALID, "rt_scene_create: out is null");
+  if (builder > RT_BUILD_DEVICE_LBVH) return fail(RT_ERR_INVALID, "rt_scene_create: unknown builder");
   *out = nullptr;
   if ((n && !spheres) || (nm && !materials)) return fail(RT_ERR_INVALID, "rt_scene_create: null array");
   if (n >= kMaxSlots) return fail(RT_ERR_LIMIT, "rt_scene_create: at most 16777199 spheres");
@@ -165,10 +171,6 @@ int rt_scene_create(const rt_sphere* spheres, size_t n, const rt_material* mater
   RT_HIP(hipGetDeviceProperties(&prop, sc->device));
   sc->num_cus = prop.multiProcessorCount;
 
-  auto t0 = std::chrono::steady_clock::now();
-  sc->host = build_bvh(spheres, n);
-  FlatBvh flat = flatten_bvh(sc->host, spheres, n);
-  auto t1 = std::chrono::steady_clock::now();
   sc->n_spheres = n;
   sc->n_materials = nm;
 
@@ -192,22 +194,52 @@ int rt_scene_create(const rt_sphere* spheres, size_t n, const rt_material* mater
       d[3] = m.type == RT_METAL ? m.param : 0.0;
     }
   }
-  for (auto& a : flat.aux) a.material |= (uint32_t)sc->material_type[a.material] << 30;
+
+  // The tree: built on the host with the reference's algorithm, or on the device (two or more
+  // spheres; a tree too deep for the traversal stack falls back to the host builder).
+  auto t0 = std::chrono::steady_clock::now();
+  const size_t max_depth = (kLdsPerCu - lds_fixed_bytes() - 64 - 16 * 1024) / (kWorkgroup * 4);
+  FlatBvh flat;
+  DeviceTree tree;
+  bool on_device = false;
+  if (builder == RT_BUILD_DEVICE_LBVH && n >= 2) {
+    hipError_t e = device_build_lbvh(spheres, n, sc->material_type.data(), nm, &tree, nullptr);
+    sc->d_nodes = tree.d_nodes;
+    sc->d_spheres = tree.d_spheres;
+    sc->d_aux = tree.d_aux;
+    RT_HIP(e);
+    if (tree.depth <= max_depth) {
+      on_device = true;
+    } else {
+      (void)hipFree(sc->d_nodes);
+      (void)hipFree(sc->d_spheres);
+      (void)hipFree(sc->d_aux);
+      sc->d_nodes = sc->d_spheres = sc->d_aux = nullptr;
+    }
+  }
+  if (!on_device) {
+    sc->host = build_bvh(spheres, n);
+    flat = flatten_bvh(sc->host, spheres, n);
+    for (auto& a : flat.aux) a.material |= (uint32_t)sc->material_type[a.material] << 30;
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  const size_t n_dev_nodes = on_device ? tree.n_nodes : flat.nodes.size();
+  const uint32_t tree_depth = on_device ? tree.depth : flat.depth;
 
   // LDS plan for one workgroup per CU: the per-lane stacks are mandatory; then, while they
   // fit, the top of the tree, the sphere records, the slots' shading data and the materials.
-  const uint32_t depth = flat.depth ? flat.depth : 1;
+  const uint32_t depth = tree_depth ? tree_depth : 1;
   const size_t stack_bytes = (size_t)depth * kWorkgroup * 4;
   const size_t reserve = lds_fixed_bytes() + 64;
   if (stack_bytes + reserve + 16 * 1024 > kLdsPerCu)
     return fail(RT_ERR_LIMIT, "rt_scene_create: BVH depth " + std::to_string(depth) + " needs more traversal stack than LDS holds");
   size_t room = kLdsPerCu - stack_bytes - reserve;
-  const size_t node_bytes = flat.nodes.size() * sizeof(DevNode), sph_bytes = flat.spheres.size() * sizeof(DevSphere);
-  const size_t aux_bytes = flat.aux.size() * sizeof(DevSphereAux), mat_bytes = nm * 32;
-  uint32_t n_nodes_lds = (uint32_t)std::min(flat.nodes.size(), room / lds_node_bytes());
+  const size_t node_bytes = n_dev_nodes * sizeof(DevNode), sph_bytes = n * sizeof(DevSphere);
+  const size_t aux_bytes = n * sizeof(DevSphereAux), mat_bytes = nm * 32;
+  uint32_t n_nodes_lds = (uint32_t)std::min(n_dev_nodes, room / lds_node_bytes());
   room -= n_nodes_lds * lds_node_bytes();
   uint32_t n_sph_lds = 0, n_aux_lds = 0, n_mat_lds = 0;
-  if (n_nodes_lds == flat.nodes.size()) {
+  if (n_nodes_lds == n_dev_nodes) {
     if (sph_bytes <= room) {
       n_sph_lds = (uint32_t)n;
       room -= sph_bytes;
@@ -219,20 +251,22 @@ int rt_scene_create(const rt_sphere* spheres, size_t n, const rt_material* mater
     }
   }
 
-  RT_HIP(hipMalloc(&sc->d_nodes, node_bytes ? node_bytes : 64));
-  RT_HIP(hipMalloc(&sc->d_spheres, sph_bytes ? sph_bytes : 32));
-  RT_HIP(hipMalloc(&sc->d_aux, aux_bytes ? aux_bytes : 16));
+  if (!on_device) {
+    RT_HIP(hipMalloc(&sc->d_nodes, node_bytes ? node_bytes : 64));
+    RT_HIP(hipMalloc(&sc->d_spheres, sph_bytes ? sph_bytes : 32));
+    RT_HIP(hipMalloc(&sc->d_aux, aux_bytes ? aux_bytes : 16));
+    if (node_bytes) RT_HIP(hipMemcpy(sc->d_nodes, flat.nodes.data(), node_bytes, hipMemcpyHostToDevice));
+    if (sph_bytes) RT_HIP(hipMemcpy(sc->d_spheres, flat.spheres.data(), sph_bytes, hipMemcpyHostToDevice));
+    if (aux_bytes) RT_HIP(hipMemcpy(sc->d_aux, flat.aux.data(), aux_bytes, hipMemcpyHostToDevice));
+  }
   RT_HIP(hipMalloc(&sc->d_materials, mat_bytes ? mat_bytes : 32));
-  if (node_bytes) RT_HIP(hipMemcpy(sc->d_nodes, flat.nodes.data(), node_bytes, hipMemcpyHostToDevice));
-  if (sph_bytes) RT_HIP(hipMemcpy(sc->d_spheres, flat.spheres.data(), sph_bytes, hipMemcpyHostToDevice));
-  if (aux_bytes) RT_HIP(hipMemcpy(sc->d_aux, flat.aux.data(), aux_bytes, hipMemcpyHostToDevice));
   if (mat_bytes) RT_HIP(hipMemcpy(sc->d_materials, mats.data(), mat_bytes, hipMemcpyHostToDevice));
 
   sc->dev.nodes = static_cast<const float4*>(sc->d_nodes);
   sc->dev.spheres = static_cast<const double2*>(sc->d_spheres);
   sc->dev.aux = static_cast<const double2*>(sc->d_aux);
   sc->dev.materials = static_cast<const double2*>(sc->d_materials);
-  sc->dev.n_nodes = (uint32_t)flat.nodes.size();
+  sc->dev.n_nodes = (uint32_t)n_dev_nodes;
   sc->dev.n_spheres = (uint32_t)n;
   sc->dev.n_materials = (uint32_t)nm;
   sc->dev.n_nodes_lds = n_nodes_lds;
@@ -240,13 +274,14 @@ int rt_scene_create(const rt_sphere* spheres, size_t n, const rt_material* mater
   sc->dev.n_aux_lds = n_aux_lds;
   sc->dev.n_materials_lds = n_mat_lds;
   sc->dev.stack_cap = depth;
-  sc->dev.root = flat.root;
-  sc->dev.bound = flat.bound;
+  sc->dev.root = on_device ? tree.root : flat.root;
+  sc->dev.bound = on_device ? tree.bound : flat.bound;
 
   sc->info.n_spheres = n;
-  sc->info.n_nodes = sc->host.nodes.size();
-  sc->info.n_device_nodes = flat.nodes.size();
-  sc->info.depth = sc->host.depth;
+  sc->info.n_nodes = on_device ? 2 * n - 1 : sc->host.nodes.size();
+  sc->info.n_device_nodes = n_dev_nodes;
+  sc->info.depth = on_device ? tree.depth : sc->host.depth;
+  sc->info.builder = on_device ? RT_BUILD_DEVICE_LBVH : RT_BUILD_HOST_SAH;
   sc->info.n_nodes_in_lds = n_nodes_lds;
   sc->info.spheres_in_lds = (n_sph_lds ? 1u : 0u) | (n_aux_lds ? 2u : 0u) | (n_mat_lds ? 4u : 0u);
   sc->info.device = (uint32_t)sc->device;
@@ -278,6 +313,7 @@ int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
 
 int rt_scene_bvh_dump(const rt_scene* sc, double* boxes, int32_t* kind, uint64_t* skip_or_count, uint64_t* leaf_indices) {
   if (!sc) return fail(RT_ERR_INVALID, "rt_scene_bvh_dump: scene is null");
+  if (sc->info.builder != RT_BUILD_HOST_SAH) return fail(RT_ERR_INVALID, "rt_scene_bvh_dump: the scene's tree was built on the device; there is no host tree to dump");
   dump_bvh(sc->host, boxes, kind, skip_or_count, leaf_indices);
   return RT_OK;
 }

@@ -1,0 +1,30 @@
+// BVH construction on the device (rt_build.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rt.h"
+
+namespace rta {
+
+// Device arrays of a finished tree, in the layout of SceneDev (rt_launch.h).  The arrays are
+// allocated with hipMalloc by the builder and owned by the caller, also when the build fails
+// half-way (free whatever is not null).
+struct DeviceTree {
+  void* d_nodes = nullptr;    // n_nodes x 64 B, breadth-first
+  void* d_spheres = nullptr;  // n x 32 B in leaf order
+  void* d_aux = nullptr;      // n x 16 B in leaf order
+  uint32_t n_nodes = 0;
+  uint32_t depth = 0;  // levels of the tree, leaves included
+  uint32_t root = 0;
+  float bound = 0.0f;
+};
+
+// Linear BVH over n >= 2 spheres (host array), one sphere per leaf.  material_type[m] is the kind
+// (0..2) of material m; it is packed next to the material index in the shading data.
+// Returns when the tree is complete.
+hipError_t device_build_lbvh(const rt_sphere* spheres, size_t n, const uint8_t* material_type, size_t n_materials, DeviceTree* out,
+                             hipStream_t stream);
+
+}  // namespace rta

@@ -1,0 +1,395 @@
+// BVH construction on the device: a linear BVH (Morton order, the hierarchy of
+// Karras 2012 built in one pass, boxes fitted bottom-up), written straight into
+// the layout the traversal kernels read.  It stands in for BVH::new
+// (src/bvh.rs:44-48) where building on the host would take longer than
+// rendering; the tree differs from the reference's binned-SAH tree, the closest
+// hits do not (they depend on the spheres only).
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "rt_build.h"
+
+namespace rta {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr uint32_t kLeafBit = 0x80000000u;
+
+struct Box6 {
+  double lo[3], hi[3];
+};
+
+__device__ __forceinline__ float round_down(double v) {
+  float f = (float)v;
+  return ((double)f > v) ? nextafterf(f, -__builtin_inff()) : f;
+}
+__device__ __forceinline__ float round_up(double v) {
+  float f = (float)v;
+  return ((double)f < v) ? nextafterf(f, __builtin_inff()) : f;
+}
+
+// Sphere::aabb (src/sphere.rs:50-52) and the box's centroid (src/aabb.rs:23-25) per sphere;
+// per block, the bounds of the centroids.
+__global__ __launch_bounds__(kThreads) void boxes_kernel(const rt_sphere* __restrict__ spheres, uint32_t n, Box6* __restrict__ prim_box,
+                                                          double* __restrict__ centroid, double* __restrict__ block_bounds) {
+  __shared__ double red[6][kThreads];
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  double c[3], lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = __builtin_inf();
+    hi[a] = -__builtin_inf();
+  }
+  if (i < n) {
+    const rt_sphere s = spheres[i];
+    Box6 b;
+    for (int a = 0; a < 3; ++a) {
+      const double p0 = s.center[a] - s.radius, p1 = s.center[a] + s.radius;
+      b.lo[a] = fmin(p0, p1);
+      b.hi[a] = fmax(p0, p1);
+      c[a] = b.lo[a] + 0.5 * (b.hi[a] - b.lo[a]);
+      centroid[3 * (size_t)i + a] = c[a];
+      lo[a] = hi[a] = c[a];
+    }
+    prim_box[i] = b;
+  }
+  for (int a = 0; a < 3; ++a) {
+    red[a][threadIdx.x] = lo[a];
+    red[3 + a][threadIdx.x] = hi[a];
+  }
+  __syncthreads();
+  for (int off = kThreads / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+      for (int a = 0; a < 3; ++a) {
+        red[a][threadIdx.x] = fmin(red[a][threadIdx.x], red[a][threadIdx.x + off]);
+        red[3 + a][threadIdx.x] = fmax(red[3 + a][threadIdx.x], red[3 + a][threadIdx.x + off]);
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) block_bounds[6 * (size_t)blockIdx.x + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(kThreads) void bounds_kernel(const double* __restrict__ block_bounds, uint32_t n_blocks, double* __restrict__ bounds) {
+  __shared__ double red[6][kThreads];
+  double lo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()}, hi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
+  for (uint32_t b = threadIdx.x; b < n_blocks; b += kThreads)
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fmin(lo[a], block_bounds[6 * (size_t)b + a]);
+      hi[a] = fmax(hi[a], block_bounds[6 * (size_t)b + 3 + a]);
+    }
+  for (int a = 0; a < 3; ++a) {
+    red[a][threadIdx.x] = lo[a];
+    red[3 + a][threadIdx.x] = hi[a];
+  }
+  __syncthreads();
+  for (int off = kThreads / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+      for (int a = 0; a < 3; ++a) {
+        red[a][threadIdx.x] = fmin(red[a][threadIdx.x], red[a][threadIdx.x + off]);
+        red[3 + a][threadIdx.x] = fmax(red[3 + a][threadIdx.x], red[3 + a][threadIdx.x + off]);
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) bounds[threadIdx.x] = red[threadIdx.x][0];
+}
+
+__device__ __forceinline__ uint64_t spread21(uint64_t v) {  // bit k of v moves to bit 3k
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+// 63-bit Morton code of each centroid inside the bounds of all centroids.
+__global__ __launch_bounds__(kThreads) void morton_kernel(const double* __restrict__ centroid, const double* __restrict__ bounds, uint32_t n,
+                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  uint64_t q[3];
+  for (int a = 0; a < 3; ++a) {
+    const double lo = bounds[a], ext = bounds[3 + a] - lo;
+    double f = ext > 0.0 ? (centroid[3 * (size_t)i + a] - lo) / ext : 0.0;
+    f = fmin(fmax(f * 2097152.0, 0.0), 2097151.0);
+    q[a] = (uint64_t)f;
+  }
+  keys[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+  vals[i] = i;
+}
+
+// Length of the common prefix of the keys at sorted positions i and j; equal keys are told apart by position.
+__device__ __forceinline__ int prefix_len(const uint64_t* __restrict__ keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint64_t a = keys[i], b = keys[j];
+  if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+  return __clzll((long long)(a ^ b));
+}
+
+// One thread per inner node i of the n - 1: its range of leaves and the split inside it.
+// Children: index of an inner node, or kLeafBit | sorted position of a leaf.
+__global__ __launch_bounds__(kThreads) void hierarchy_kernel(const uint64_t* __restrict__ keys, int n, uint32_t* __restrict__ left,
+                                                              uint32_t* __restrict__ right, uint32_t* __restrict__ parent_inner,
+                                                              uint32_t* __restrict__ parent_leaf) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = prefix_len(keys, n, i, i + 1) > prefix_len(keys, n, i, i - 1) ? 1 : -1;
+  const int dmin = prefix_len(keys, n, i, i - d);
+  int lmax = 2;
+  while (prefix_len(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2)
+    if (prefix_len(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = prefix_len(keys, n, i, j);
+  int s = 0, t = l;
+  do {
+    t = (t + 1) / 2;
+    if (prefix_len(keys, n, i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + min(d, 0);
+  const int lo = min(i, j), hi = max(i, j);
+  if (lo == gamma) {
+    left[i] = kLeafBit | (uint32_t)gamma;
+    parent_leaf[gamma] = (uint32_t)i;
+  } else {
+    left[i] = (uint32_t)gamma;
+    parent_inner[gamma] = (uint32_t)i;
+  }
+  if (hi == gamma + 1) {
+    right[i] = kLeafBit | (uint32_t)(gamma + 1);
+    parent_leaf[gamma + 1] = (uint32_t)i;
+  } else {
+    right[i] = (uint32_t)(gamma + 1);
+    parent_inner[gamma + 1] = (uint32_t)i;
+  }
+  if (i == 0) parent_inner[0] = 0xffffffffu;
+}
+
+__device__ __forceinline__ Box6 child_box(uint32_t ref, const Box6* __restrict__ prim_box, const uint32_t* __restrict__ vals,
+                                           const Box6* node_box) {
+  if (ref & kLeafBit) return prim_box[vals[ref & ~kLeafBit]];
+  // written by another thread of this launch: read past the caches of this CU
+  Box6 b;
+  const double* p = reinterpret_cast<const double*>(node_box + ref);
+  for (int a = 0; a < 3; ++a) {
+    b.lo[a] = __builtin_nontemporal_load(p + a);
+    b.hi[a] = __builtin_nontemporal_load(p + 3 + a);
+  }
+  return b;
+}
+
+// One thread per leaf climbs towards the root; the second thread to reach a node fits its box.
+__global__ __launch_bounds__(kThreads) void fit_kernel(int n, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                        const uint32_t* __restrict__ parent_inner, const uint32_t* __restrict__ parent_leaf,
+                                                        const Box6* __restrict__ prim_box, const uint32_t* __restrict__ vals, Box6* node_box,
+                                                        uint32_t* arrivals) {
+  const int k = blockIdx.x * kThreads + threadIdx.x;
+  if (k >= n) return;
+  uint32_t node = parent_leaf[k];
+  while (node != 0xffffffffu) {
+    __threadfence();
+    if (atomicAdd(&arrivals[node], 1u) == 0u) return;  // the sibling subtree is not finished yet
+    __threadfence();
+    const Box6 a = child_box(left[node], prim_box, vals, node_box), b = child_box(right[node], prim_box, vals, node_box);
+    Box6 u;
+    for (int x = 0; x < 3; ++x) {
+      u.lo[x] = fmin(a.lo[x], b.lo[x]);
+      u.hi[x] = fmax(a.hi[x], b.hi[x]);
+    }
+    node_box[node] = u;
+    node = parent_inner[node];
+  }
+}
+
+// Level of each inner node (root = 1); the deepest level seen.
+__global__ __launch_bounds__(kThreads) void level_kernel(int n_inner, const uint32_t* __restrict__ parent_inner, uint32_t* __restrict__ level,
+                                                          uint32_t* __restrict__ ids, uint32_t* max_level) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n_inner) return;
+  uint32_t l = 1, p = parent_inner[i];
+  while (p != 0xffffffffu) {
+    ++l;
+    p = parent_inner[p];
+  }
+  level[i] = l;
+  ids[i] = (uint32_t)i;
+  atomicMax(max_level, l);
+}
+
+__global__ __launch_bounds__(kThreads) void rank_kernel(int n_inner, const uint32_t* __restrict__ order, uint32_t* __restrict__ new_of) {
+  const int k = blockIdx.x * kThreads + threadIdx.x;
+  if (k < n_inner) new_of[order[k]] = (uint32_t)k;
+}
+
+// The 64-byte traversal node of each inner node, at its breadth-first rank.
+__global__ __launch_bounds__(kThreads) void emit_nodes_kernel(int n_inner, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                               const uint32_t* __restrict__ new_of, const Box6* __restrict__ prim_box,
+                                                               const uint32_t* __restrict__ vals, const Box6* __restrict__ node_box,
+                                                               float4* __restrict__ nodes, float* __restrict__ bound) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n_inner) return;
+  uint32_t r0 = left[i], r1 = right[i];
+  Box6 b0 = (r0 & kLeafBit) ? prim_box[vals[r0 & ~kLeafBit]] : node_box[r0];
+  Box6 b1 = (r1 & kLeafBit) ? prim_box[vals[r1 & ~kLeafBit]] : node_box[r1];
+  // split axis: where the children's centres are furthest apart; child 0 is the lower one, as in the host tree
+  int axis = 0;
+  double best = -1.0, diff[3];
+  for (int a = 0; a < 3; ++a) {
+    diff[a] = (b1.lo[a] + b1.hi[a]) - (b0.lo[a] + b0.hi[a]);
+    if (fabs(diff[a]) > best) {
+      best = fabs(diff[a]);
+      axis = a;
+    }
+  }
+  if (diff[axis] < 0.0) {
+    const Box6 tb = b0;
+    b0 = b1;
+    b1 = tb;
+    const uint32_t tr = r0;
+    r0 = r1;
+    r1 = tr;
+  }
+  auto ref = [&](uint32_t r) { return (r & kLeafBit) ? (kLeafBit | (1u << 24) | (r & ~kLeafBit)) : new_of[r]; };
+  float4 q0 = make_float4(round_down(b0.lo[0]), round_up(b0.hi[0]), round_down(b1.lo[0]), round_up(b1.hi[0]));
+  float4 q1 = make_float4(round_down(b0.lo[1]), round_up(b0.hi[1]), round_down(b1.lo[1]), round_up(b1.hi[1]));
+  float4 q2 = make_float4(round_down(b0.lo[2]), round_up(b0.hi[2]), round_down(b1.lo[2]), round_up(b1.hi[2]));
+  float4 q3 = make_float4(__uint_as_float(ref(r0)), __uint_as_float(ref(r1)), __uint_as_float((uint32_t)axis), 0.0f);
+  float4* dst = nodes + 4 * (size_t)new_of[i];
+  dst[0] = q0;
+  dst[1] = q1;
+  dst[2] = q2;
+  dst[3] = q3;
+  if (i == 0) {  // the root's box bounds every plane of the tree
+    const Box6 rb = node_box[0];
+    double m = 0.0;
+    for (int a = 0; a < 3; ++a) m = fmax(m, fmax(fabs(rb.lo[a]), fabs(rb.hi[a])));
+    *bound = round_up(m);
+  }
+}
+
+// Sphere records and shading data in Morton order (slot k = sorted position k).
+__global__ __launch_bounds__(kThreads) void emit_spheres_kernel(const rt_sphere* __restrict__ spheres, const uint32_t* __restrict__ vals, uint32_t n,
+                                                                 const uint8_t* __restrict__ material_type, double* __restrict__ out_spheres,
+                                                                 double2* __restrict__ out_aux) {
+  const uint32_t k = blockIdx.x * kThreads + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t i = vals[k];
+  const rt_sphere s = spheres[i];
+  double* o = out_spheres + 4 * (size_t)k;
+  o[0] = s.center[0];
+  o[1] = s.center[1];
+  o[2] = s.center[2];
+  o[3] = s.radius;
+  const uint32_t mat = s.material | ((uint32_t)material_type[s.material] << 30);
+  const unsigned long long bits = (unsigned long long)mat | ((unsigned long long)i << 32);
+  out_aux[k] = make_double2(1.0 / s.radius, __longlong_as_double((long long)bits));
+}
+
+struct Scratch {
+  void* p = nullptr;
+  ~Scratch() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <class T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+#define RTB(call)                   \
+  do {                              \
+    hipError_t e_ = (call);         \
+    if (e_ != hipSuccess) return e_; \
+  } while (0)
+
+}  // namespace
+
+hipError_t device_build_lbvh(const rt_sphere* h_spheres, size_t n_, const uint8_t* h_material_type, size_t n_materials, DeviceTree* out,
+                             hipStream_t stream) {
+  const uint32_t n = (uint32_t)n_;
+  const uint32_t n_inner = n - 1;  // the caller guarantees n >= 2
+  const unsigned blocks = (n + kThreads - 1) / kThreads, blocks_inner = (n_inner + kThreads - 1) / kThreads;
+
+  Scratch d_in, d_mtype, prim_box, centroid, block_bounds, bounds, keys, keys2, vals, vals2, left, right, parent_inner, parent_leaf, node_box,
+      arrivals, level, level2, ids, order, new_of, misc, sort_tmp;
+  RTB(d_in.alloc((size_t)n * sizeof(rt_sphere)));
+  RTB(d_mtype.alloc(n_materials));
+  RTB(hipMemcpyAsync(d_in.p, h_spheres, (size_t)n * sizeof(rt_sphere), hipMemcpyHostToDevice, stream));
+  RTB(hipMemcpyAsync(d_mtype.p, h_material_type, n_materials, hipMemcpyHostToDevice, stream));
+  RTB(prim_box.alloc((size_t)n * sizeof(Box6)));
+  RTB(centroid.alloc((size_t)n * 24));
+  RTB(block_bounds.alloc((size_t)blocks * 48));
+  RTB(bounds.alloc(48));
+  RTB(keys.alloc((size_t)n * 8));
+  RTB(keys2.alloc((size_t)n * 8));
+  RTB(vals.alloc((size_t)n * 4));
+  RTB(vals2.alloc((size_t)n * 4));
+  RTB(left.alloc((size_t)n_inner * 4));
+  RTB(right.alloc((size_t)n_inner * 4));
+  RTB(parent_inner.alloc((size_t)n_inner * 4));
+  RTB(parent_leaf.alloc((size_t)n * 4));
+  RTB(node_box.alloc((size_t)n_inner * sizeof(Box6)));
+  RTB(arrivals.alloc((size_t)n_inner * 4));
+  RTB(level.alloc((size_t)n_inner * 4));
+  RTB(level2.alloc((size_t)n_inner * 4));
+  RTB(ids.alloc((size_t)n_inner * 4));
+  RTB(order.alloc((size_t)n_inner * 4));
+  RTB(new_of.alloc((size_t)n_inner * 4));
+  RTB(misc.alloc(16));  // [0] deepest level (u32), [1] bound (f32)
+  RTB(hipMemsetAsync(arrivals.p, 0, (size_t)n_inner * 4, stream));
+  RTB(hipMemsetAsync(misc.p, 0, 16, stream));
+
+  hipLaunchKernelGGL(boxes_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, prim_box.as<Box6>(), centroid.as<double>(),
+                     block_bounds.as<double>());
+  hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(kThreads), 0, stream, block_bounds.as<double>(), blocks, bounds.as<double>());
+  hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(kThreads), 0, stream, centroid.as<double>(), bounds.as<double>(), n, keys.as<uint64_t>(),
+                     vals.as<uint32_t>());
+  RTB(hipGetLastError());
+
+  size_t tmp_bytes = 0, tmp_bytes2 = 0;
+  RTB(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), n, 0, 63,
+                                stream));
+  RTB(rocprim::radix_sort_pairs(nullptr, tmp_bytes2, level.as<uint32_t>(), level2.as<uint32_t>(), ids.as<uint32_t>(), order.as<uint32_t>(), n_inner,
+                                0, 8, stream));
+  RTB(sort_tmp.alloc(tmp_bytes > tmp_bytes2 ? tmp_bytes : tmp_bytes2));
+  RTB(rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), n, 0, 63,
+                                stream));
+
+  hipLaunchKernelGGL(hierarchy_kernel, dim3(blocks_inner), dim3(kThreads), 0, stream, keys2.as<uint64_t>(), (int)n, left.as<uint32_t>(),
+                     right.as<uint32_t>(), parent_inner.as<uint32_t>(), parent_leaf.as<uint32_t>());
+  hipLaunchKernelGGL(fit_kernel, dim3(blocks), dim3(kThreads), 0, stream, (int)n, left.as<uint32_t>(), right.as<uint32_t>(),
+                     parent_inner.as<uint32_t>(), parent_leaf.as<uint32_t>(), prim_box.as<Box6>(), vals2.as<uint32_t>(), node_box.as<Box6>(),
+                     arrivals.as<uint32_t>());
+  hipLaunchKernelGGL(level_kernel, dim3(blocks_inner), dim3(kThreads), 0, stream, (int)n_inner, parent_inner.as<uint32_t>(), level.as<uint32_t>(),
+                     ids.as<uint32_t>(), misc.as<uint32_t>());
+  RTB(hipGetLastError());
+  // Breadth-first numbering: a stable sort of the node ids by level (levels stay below 2^8: 63 key bits and 32 index bits).
+  RTB(rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes2, level.as<uint32_t>(), level2.as<uint32_t>(), ids.as<uint32_t>(), order.as<uint32_t>(), n_inner,
+                                0, 8, stream));
+  hipLaunchKernelGGL(rank_kernel, dim3(blocks_inner), dim3(kThreads), 0, stream, (int)n_inner, order.as<uint32_t>(), new_of.as<uint32_t>());
+
+  RTB(hipMalloc(&out->d_nodes, (size_t)n_inner * 64));
+  RTB(hipMalloc(&out->d_spheres, (size_t)n * 32));
+  RTB(hipMalloc(&out->d_aux, (size_t)n * 16));
+  hipLaunchKernelGGL(emit_nodes_kernel, dim3(blocks_inner), dim3(kThreads), 0, stream, (int)n_inner, left.as<uint32_t>(), right.as<uint32_t>(),
+                     new_of.as<uint32_t>(), prim_box.as<Box6>(), vals2.as<uint32_t>(), node_box.as<Box6>(), static_cast<float4*>(out->d_nodes),
+                     misc.as<float>() + 1);
+  hipLaunchKernelGGL(emit_spheres_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), vals2.as<uint32_t>(), n,
+                     d_mtype.as<uint8_t>(), static_cast<double*>(out->d_spheres), static_cast<double2*>(out->d_aux));
+  RTB(hipGetLastError());
+
+  uint32_t host_misc[4] = {0, 0, 0, 0};
+  RTB(hipMemcpyAsync(host_misc, misc.p, 16, hipMemcpyDeviceToHost, stream));
+  RTB(hipStreamSynchronize(stream));
+  out->n_nodes = n_inner;
+  out->depth = host_misc[0] + 1;  // inner levels plus the leaves
+  std::memcpy(&out->bound, &host_misc[1], 4);
+  out->root = 0;  // the root is alone on level 1, so it is first in breadth-first order
+  return hipSuccess;
+}
+
+}  // namespace rta

@@ -5,6 +5,8 @@ use std::os::raw::{c_char, c_int, c_void};
 pub const RT_LAMBERTIAN: u32 = 0;
 pub const RT_METAL: u32 = 1;
 pub const RT_DIELECTRIC: u32 = 2;
+pub const RT_BUILD_HOST_SAH: u32 = 0;
+pub const RT_BUILD_DEVICE_LBVH: u32 = 1;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -72,6 +74,14 @@ extern "C" {
         n_spheres: usize,
         materials: *const rt_material,
         n_materials: usize,
+        out: *mut *mut rt_scene,
+    ) -> c_int;
+    pub fn rt_scene_create_ex(
+        spheres: *const rt_sphere,
+        n_spheres: usize,
+        materials: *const rt_material,
+        n_materials: usize,
+        builder: u32,
         out: *mut *mut rt_scene,
     ) -> c_int;
     pub fn rt_scene_destroy(scene: *mut rt_scene) -> c_int;

@@ -479,3 +479,80 @@ def test_full_size_fields_against_brute_force():
                 cam.render_sum(world, seed=2, spp_begin=s0, spp_end=s1, tile=tile, rgb_sum=parts)
         assert np.abs(parts - whole).max() <= 1e-12 * np.abs(whole).max()
         world.close()
+
+
+# ---- the tree built on the device (linear BVH) must find the same closest hits as the reference's tree ----
+def test_device_built_tree_finds_the_same_hits(oracle, rtiow):
+    spheres, materials = rtiow
+    world = rt.BVH(spheres, materials, builder=rt.BUILD_DEVICE_LBVH)
+    info = world.info()
+    assert info["builder"] == rt.BUILD_DEVICE_LBVH and info["n_device_nodes"] == len(spheres) - 1 and info["depth"] < 36
+    oworld = _oracle_scene(oracle, spheres, materials)
+    cfg = rt.config_rtiow(image_width=128, samples_per_pixel=4, max_depth=50)
+    rng = np.random.default_rng(31)
+    n = 1 << 15
+    ijs = np.stack([rng.integers(0, 128, n), rng.integers(0, 72, n), rng.integers(0, 4, n)], axis=1)
+    org, d = oracle.primary_rays(cfg.record().view(oracle.CONFIG_DTYPE), 12345, ijs)
+    ties, rel_t, dn = compare_hits(world.trace_batch(org, d), oworld.trace_batch(org, d))
+    org2, d2 = _secondary_rays(spheres, rng, n)
+    ties2, rel_t2, dn2 = compare_hits(world.trace_batch(org2, d2), oworld.trace_batch(org2, d2))
+    print("device-built tree: ties %d + %d, rel dt %.2e %.2e" % (ties, ties2, rel_t, rel_t2))
+    assert ties + ties2 <= 8
+    # a render is the same function of the hits
+    got, stats = cfg.camera().render_sum(world, seed=5)
+    want, ostats = oworld.render(cfg.record().view(oracle.CONFIG_DTYPE), 5, 0, 4, nthreads=8)
+    frac, worst = _pixel_agreement(got, want)
+    assert frac >= 0.97 and abs(stats["rays"] - int(ostats[0])) <= 0.002 * int(ostats[0])
+    with pytest.raises(rt.RtError):
+        world.dump()  # there is no host tree
+    world.close()
+
+
+def test_device_built_tree_large_and_degenerate():
+    # 1e5 spheres against brute force; then inputs that stress the Morton order: all centres equal, collinear
+    # centres, two spheres, and clusters far apart (few distinct high bits)
+    spheres, materials = rt.scene_field(3, 100000, 0.15, 0.15)
+    world = rt.BVH(spheres, materials, builder=rt.BUILD_DEVICE_LBVH)
+    info = world.info()
+    assert info["builder"] == rt.BUILD_DEVICE_LBVH and info["build_ms"] < 500.0
+    rng = np.random.default_rng(3)
+    aim = spheres["center"][rng.integers(1, 100001, 256)]
+    org = aim + np.array([0.0, 6.0, 0.0]) + rng.uniform(-4.0, 4.0, (256, 3))
+    d = aim + rng.normal(size=(256, 3)) * 0.15 - org
+    got = world.trace_batch(org, d)
+    prim, t = _brute_force_hits(spheres, org, d)
+    assert np.array_equal(got["prim"], prim) and (np.abs(got["t"][prim >= 0] - t[prim >= 0]) <= 1e-9 * t[prim >= 0]).all()
+    world.close()
+    mat = np.zeros(1, dtype=rt.MATERIAL_DTYPE)
+    mat["albedo"] = (0.5, 0.5, 0.5)
+    cases = {}
+    same = np.zeros(50, dtype=rt.SPHERE_DTYPE)
+    same["center"] = (0.0, 0.0, 5.0)
+    same["radius"] = np.linspace(0.5, 2.0, 50)
+    cases["same centre"] = same
+    line = np.zeros(200, dtype=rt.SPHERE_DTYPE)
+    line["center"][:, 0] = np.arange(200) * 0.5 - 50
+    line["center"][:, 2] = 5.0
+    line["radius"] = 0.3
+    cases["collinear"] = line
+    two = np.zeros(2, dtype=rt.SPHERE_DTYPE)
+    two["center"] = [[-1, 0, 5], [1, 0, 5]]
+    two["radius"] = 0.9
+    cases["two"] = two
+    cl = np.zeros(300, dtype=rt.SPHERE_DTYPE)
+    cl["center"] = rng.normal(size=(300, 3)) * 0.5 + np.repeat(np.array([[-1e4, 0, 5], [0, 0, 5], [1e4, 3, 5]]), 100, axis=0)
+    cl["radius"] = 0.2
+    cases["clusters"] = cl
+    for name, sp in cases.items():
+        w = rt.BVH(sp, mat, builder=rt.BUILD_DEVICE_LBVH)
+        aim = sp["center"][rng.integers(0, len(sp), 512)]
+        org = aim + rng.normal(size=(512, 3)) * 3.0 + np.array([0.0, 0.0, -8.0])
+        d = aim + rng.normal(size=(512, 3)) * 0.2 - org
+        got = w.trace_batch(org, d)
+        prim, t = _brute_force_hits(sp, org, d)
+        hit = prim >= 0
+        assert np.array_equal(got["prim"] >= 0, hit), name
+        assert (np.abs(got["t"][hit] - t[hit]) <= 1e-9 * np.abs(t[hit])).all(), name  # concentric spheres tie in index, never in distance
+        if name != "same centre":
+            assert np.array_equal(got["prim"], prim), name
+        w.close()

@@ -27,6 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="c1,c3,c4,c5")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--builder", choices=["host", "device"], default="host")
     args = ap.parse_args()
     import torch
 
@@ -43,7 +44,7 @@ def main():
             spheres, materials = rt.scene_field(seed, n, pl, pm, fz)
             cfg = rt.config_field(n, width, spp, depth)
         t1 = time.perf_counter()
-        world = rt.BVH(spheres, materials)
+        world = rt.BVH(spheres, materials, builder=rt.BUILD_DEVICE_LBVH if args.builder == "device" else rt.BUILD_HOST_SAH)
         t2 = time.perf_counter()
         cam = cfg.camera()
         frame = torch.zeros((cam.image_height, width, 3), dtype=torch.float64, device="cuda")
@@ -52,7 +53,7 @@ def main():
         info = world.info()
         print(json.dumps({
             "config": name, "spheres": len(spheres), "width": width, "height": cam.image_height, "spp": spp, "depth": depth,
-            "scene_gen_s": t1 - t0, "bvh_build_upload_s": t2 - t1, "host_build_ms": info["build_ms"], "device_nodes": info["n_device_nodes"],
+            "scene_gen_s": t1 - t0, "bvh_build_upload_s": t2 - t1, "builder": args.builder, "depth_levels": info["depth"], "host_build_ms": info["build_ms"], "device_nodes": info["n_device_nodes"],
             "nodes_in_lds": info["n_nodes_in_lds"], "device_bytes": info["device_bytes"], "render_ms": st["kernel_ms"], "launches": st["launches"],
             "rays": st["rays"], "mean_path_length": st["rays"] / float(st["samples"]), "Mrays_per_s": st["rays"] / st["kernel_ms"] / 1e3,
             "mean_radiance": float(frame.mean().item()) / spp,
