@@ -108,6 +108,7 @@ def main():
     if distributed:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    rt.set_device(local_rank)  # the library's HIP runtime is not torch's: select the rank's GPU there too
     spheres, materials = rt.scene_rtiow(1)
     world = rt.BVH(spheres, materials)
     cfg = rt.config_rtiow(args.width, args.spp, args.depth)
@@ -127,6 +128,7 @@ def main():
 
     def step():
         frame.zero_()
+        torch.cuda.synchronize()  # torch's stream and the library's are not ordered with each other
         if weak:
             render_sample_split(render, frame, 0, total_spp, rank, world_size)
         else:

@@ -119,6 +119,14 @@ typedef struct rt_scene rt_scene;
 /* Message of the last failure on this thread ("" if none). */
 const char* rt_last_error(void);
 
+/* The library's current HIP device (scenes are created on it), for callers that do not share
+ * the library's HIP runtime: a process whose other GPU code brings its own copy of the runtime
+ * (a PyTorch wheel does) selects the device here as well as there.  Callers linked against the
+ * same libamdhip64 can simply use hipSetDevice. */
+int rt_device_count(int* count);
+int rt_device_set(int ordinal);
+int rt_device_get(int* ordinal);
+
 /* `Config::new()` defaults (src/camera.rs:15-26). */
 void rt_config_default(rt_config* cfg);
 

@@ -66,6 +66,9 @@ BUILD_HOST_SAH, BUILD_DEVICE_LBVH = 0, 1
 # Every symbol include/rt.h declares.
 EXPORTS = [
     "rt_last_error",
+    "rt_device_count",
+    "rt_device_set",
+    "rt_device_get",
     "rt_config_default",
     "rt_camera_derive",
     "rt_scene_create",

@@ -301,6 +301,24 @@ class Camera:
         return {k: stats[k][0].item() for k in RENDER_STATS_DTYPE.names}
 
 
+def device_count():
+    n = C.c_int(0)
+    check(_lib.lib().rt_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(ordinal):
+    """Selects the HIP device of the library's own runtime (scenes are created on it).  With PyTorch in the
+    process, call this with the same ordinal as torch.cuda.set_device: the wheel brings its own HIP runtime."""
+    check(_lib.lib().rt_device_set(C.c_int(ordinal)))
+
+
+def get_device():
+    n = C.c_int(0)
+    check(_lib.lib().rt_device_get(C.byref(n)))
+    return n.value
+
+
 def quantise(rgb_sum, samples_per_pixel):
     """`write_colour` (src/camera.rs:85-95): N x 3 bytes."""
     rgb = np.ascontiguousarray(np.asarray(rgb_sum, dtype=np.float64).reshape(-1, 3))

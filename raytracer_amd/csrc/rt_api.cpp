@@ -118,6 +118,21 @@ extern "C" {
 
 const char* rt_last_error(void) { return g_error.c_str(); }
 
+int rt_device_count(int* count) {
+  if (!count) return fail(RT_ERR_INVALID, "rt_device_count: null argument");
+  RT_HIP(hipGetDeviceCount(count));
+  return RT_OK;
+}
+int rt_device_set(int ordinal) {
+  RT_HIP(hipSetDevice(ordinal));
+  return RT_OK;
+}
+int rt_device_get(int* ordinal) {
+  if (!ordinal) return fail(RT_ERR_INVALID, "rt_device_get: null argument");
+  RT_HIP(hipGetDevice(ordinal));
+  return RT_OK;
+}
+
 void rt_config_default(rt_config* cfg) {
   if (cfg) config_default(cfg);
 }

@@ -108,12 +108,14 @@ def test_device_quantise_equals_host_quantise():
     want = rt.quantise(vals.reshape(-1, 3), spp)
     dev = torch.from_numpy(vals).cuda()
     out = torch.zeros(3 * n_px + 2, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # torch's stream and the library's are not ordered with each other
     rt.quantise_device(dev.data_ptr(), n_px, spp, out.data_ptr())
     got = out[: 3 * n_px].cpu().numpy().reshape(-1, 3)
     assert np.array_equal(got, want)
     odd = vals[:5 * 3 + 0][: 15].copy()  # an odd number of components goes through the tail path
     dev = torch.from_numpy(odd).cuda()
     out = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     rt.quantise_device(dev.data_ptr(), 5, spp, out.data_ptr())
     assert np.array_equal(out[:15].cpu().numpy().reshape(-1, 3), rt.quantise(odd.reshape(-1, 3), spp))
 

@@ -30,6 +30,7 @@ for r in range(a.rounds):  # interleaved rounds in one process
     for v in a.values:
         rt._lib.check(L.rt_debug_set(a.name.encode(), C.c_double(v)))
         frame.zero_()
+        torch.cuda.synchronize()
         st = cam.render_device(world, frame.data_ptr(), seed=12345, spp_begin=0, spp_end=a.spp)
         g = st["rays"] / st["kernel_ms"] / 1e6
         best.setdefault(v, []).append(g)

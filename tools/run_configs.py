@@ -48,6 +48,7 @@ def main():
         t2 = time.perf_counter()
         cam = cfg.camera()
         frame = torch.zeros((cam.image_height, width, 3), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
         st = cam.render_device(world, frame.data_ptr(), seed=12345)
         torch.cuda.synchronize()
         info = world.info()
