@@ -222,8 +222,8 @@ __device__ __forceinline__ bool box_test(const RayBox& q, f32x2 bx, f32x2 by, f3
 }
 // One box given by the planes the ray meets first (nx, ny, nz) and last (fx, fy, fz) on each axis.
 __device__ __forceinline__ bool box_test_sorted(const RayBox& q, float nx, float ny, float nz, float fx, float fy, float fz, float tminf,
-                                                float tmaxf) {
-  float tn = fmaxf(fmaxf(fmaf(nx, q.rx, q.nx.x), fmaf(ny, q.ry, q.ny.x)), fmaxf(fmaf(nz, q.rz, q.nz.x), tminf));
+                                                float tmaxf, float& tn) {
+  tn = fmaxf(fmaxf(fmaf(nx, q.rx, q.nx.x), fmaf(ny, q.ry, q.ny.x)), fmaxf(fmaf(nz, q.rz, q.nz.x), tminf));
   float tf = fminf(fminf(fmaf(fx, q.rx, q.nx.y), fmaf(fy, q.ry, q.ny.y)), fminf(fmaf(fz, q.rz, q.nz.y), tmaxf));
   return tn <= tf;
 }
@@ -307,15 +307,18 @@ __device__ __forceinline__ void fetch_sphere(const TreeView& tv, uint32_t slot, 
 
 // State of one lane's closest-hit query, BVH::hit (src/bvh.rs:50-84).
 //
-// Order of visits is the reference's: at a split the child on the side the
-// ray comes from goes first (right child first when the direction is negative
-// on the split axis, src/bvh.rs:64-68), spheres of a leaf in stored order, and
-// a later hit replaces the current one only if strictly closer
-// (Interval::surrounds, src/ray.rs:35-37).  The reference pushes both children
-// and tests each node's own box when it is popped; here both child boxes are
-// tested at the parent, the first child that is hit becomes current and the
-// other is pushed.  `stack` is this lane's column of the LDS stack, entries
-// `stride` words apart; the tree is never deeper than its capacity.
+// The reference pushes both children of a split and tests each node's own box
+// when it is popped, taking first the child on the side the ray comes from
+// (src/bvh.rs:64-68).  Here both child boxes are tested at the parent; of two
+// children that are hit the one whose box the ray enters first becomes
+// current (nodes read from LDS; for nodes read from global memory the side
+// the ray comes from on the split axis, as in the reference) and the other is
+// pushed.  The closest hit does not depend on the order of visits: a later hit
+// replaces the current one only if strictly closer (Interval::surrounds,
+// src/ray.rs:35-37), spheres of a leaf are tested in stored order, and only two
+// different spheres hit at exactly the same distance could be told apart by
+// it.  `stack` is this lane's column of the LDS stack, entries `stride` words
+// apart; the tree is never deeper than its capacity.
 struct Trav {
   D3 o, d;
   RayBox q;
@@ -366,11 +369,12 @@ template <bool kAllLds>
 __device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, lds_u32* stack, uint32_t stride, float tminf) {
   f32x4 q3;
   bool h0, h1;
+  float tn0 = 0.0f, tn1 = 0.0f;
   if (kAllLds || tr.cur < tv.n_lds) {
     f32x4 X, Y, Z;
     fetch_node_lds(tv, tr.cur, tr.offx, tr.offy, tr.offz, X, Y, Z, q3);
-    h0 = box_test_sorted(tr.q, X.x, Y.x, Z.x, X.z, Y.z, Z.z, tminf, tr.tmaxf);
-    h1 = box_test_sorted(tr.q, X.y, Y.y, Z.y, X.w, Y.w, Z.w, tminf, tr.tmaxf);
+    h0 = box_test_sorted(tr.q, X.x, Y.x, Z.x, X.z, Y.z, Z.z, tminf, tr.tmaxf, tn0);
+    h1 = box_test_sorted(tr.q, X.y, Y.y, Z.y, X.w, Y.w, Z.w, tminf, tr.tmaxf, tn1);
   } else {
     f32x4 q0, q1, q2;
     fetch_node_global(tv, tr.cur, q0, q1, q2, q3);
@@ -378,7 +382,7 @@ __device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, ld
     h1 = box_test(tr.q, f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, tminf, tr.tmaxf);
   }
   const uint32_t ref0 = __float_as_uint(q3.x), ref1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
-  const bool swap = ((tr.sgn >> axis) & 1u) != 0u;
+  const bool swap = (kAllLds || tr.cur < tv.n_lds) ? (tn1 < tn0) : (((tr.sgn >> axis) & 1u) != 0u);
   // Selects instead of a three-way branch: only the push and the pop are predicated.
   const uint32_t near = swap ? ref1 : ref0, far = swap ? ref0 : ref1;
   const bool both = h0 && h1;
