@@ -212,11 +212,11 @@ __device__ __forceinline__ float f32_above(double v) {  // smallest f32 >= v
   return ((double)f < v) ? nextafterf(f, __builtin_inff()) : f;
 }
 // One box given as (lo, hi) pairs per axis: does the ray cross it within [tminf, tmaxf]?
-__device__ __forceinline__ bool box_test(const RayBox& q, f32x2 bx, f32x2 by, f32x2 bz, float tminf, float tmaxf) {
+__device__ __forceinline__ bool box_test(const RayBox& q, f32x2 bx, f32x2 by, f32x2 bz, float tminf, float tmaxf, float& tn) {
   f32x2 tx = f32x2{fmaf(bx.x, q.rx, q.cx.x), fmaf(bx.y, q.rx, q.cx.y)};
   f32x2 ty = f32x2{fmaf(by.x, q.ry, q.cy.x), fmaf(by.y, q.ry, q.cy.y)};
   f32x2 tz = f32x2{fmaf(bz.x, q.rz, q.cz.x), fmaf(bz.y, q.rz, q.cz.y)};
-  float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tminf));
+  tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), tminf));
   float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tmaxf));
   return tn <= tf;
 }
@@ -311,9 +311,7 @@ __device__ __forceinline__ void fetch_sphere(const TreeView& tv, uint32_t slot, 
 // when it is popped, taking first the child on the side the ray comes from
 // (src/bvh.rs:64-68).  Here both child boxes are tested at the parent; of two
 // children that are hit the one whose box the ray enters first becomes
-// current (nodes read from LDS; for nodes read from global memory the side
-// the ray comes from on the split axis, as in the reference) and the other is
-// pushed.  The closest hit does not depend on the order of visits: a later hit
+// current and the other is pushed.  The closest hit does not depend on the order of visits: a later hit
 // replaces the current one only if strictly closer (Interval::surrounds,
 // src/ray.rs:35-37), spheres of a leaf are tested in stored order, and only two
 // different spheres hit at exactly the same distance could be told apart by
@@ -324,7 +322,6 @@ struct Trav {
   RayBox q;
   double t_best;
   float tmaxf;
-  uint32_t sgn;  // bit a set: direction negative on axis a
   uint32_t offx, offy, offz;  // byte offset, inside a node staged in LDS, of the copy of each axis to read
   uint32_t cur, sp;
   uint32_t tos;  // the top of the stack lives here; `sp` entries below it are in LDS
@@ -337,7 +334,6 @@ __device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D
   tr.q = ray_box(o, d, tv.bound);
   tr.t_best = t_max;
   tr.tmaxf = (t_max < 3.0e38) ? f32_above(t_max) : __builtin_inff();
-  tr.sgn = (d.x < 0.0 ? 1u : 0u) | (d.y < 0.0 ? 2u : 0u) | (d.z < 0.0 ? 4u : 0u);
   // The copy must match the sign the node test sees, which is that of the f32 reciprocal.
   tr.offx = tr.q.rx < 0.0f ? 16u : 0u;
   tr.offy = tr.q.ry < 0.0f ? 48u : 32u;
@@ -378,11 +374,11 @@ __device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, ld
   } else {
     f32x4 q0, q1, q2;
     fetch_node_global(tv, tr.cur, q0, q1, q2, q3);
-    h0 = box_test(tr.q, f32x2{q0.x, q0.y}, f32x2{q1.x, q1.y}, f32x2{q2.x, q2.y}, tminf, tr.tmaxf);
-    h1 = box_test(tr.q, f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, tminf, tr.tmaxf);
+    h0 = box_test(tr.q, f32x2{q0.x, q0.y}, f32x2{q1.x, q1.y}, f32x2{q2.x, q2.y}, tminf, tr.tmaxf, tn0);
+    h1 = box_test(tr.q, f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, tminf, tr.tmaxf, tn1);
   }
-  const uint32_t ref0 = __float_as_uint(q3.x), ref1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
-  const bool swap = (kAllLds || tr.cur < tv.n_lds) ? (tn1 < tn0) : (((tr.sgn >> axis) & 1u) != 0u);
+  const uint32_t ref0 = __float_as_uint(q3.x), ref1 = __float_as_uint(q3.y);
+  const bool swap = tn1 < tn0;  // of two children that are hit, the one entered first is visited first
   // Selects instead of a three-way branch: only the push and the pop are predicated.
   const uint32_t near = swap ? ref1 : ref0, far = swap ? ref0 : ref1;
   const bool both = h0 && h1;

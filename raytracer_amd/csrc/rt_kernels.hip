@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void slab_batch_kernel(const float4* __restric
   double t_min = interval[2 * i], t_max = interval[2 * i + 1];
   float tminf = f32_below(t_min);
   float tmaxf = (t_max < 3.0e38) ? f32_above(t_max) : __builtin_inff();
-  hit[i] = box_test(q, f32x2{lo.x, hi.x}, f32x2{lo.y, hi.y}, f32x2{lo.z, hi.z}, tminf, tmaxf) ? 1 : 0;
+  float tn;
+  hit[i] = box_test(q, f32x2{lo.x, hi.x}, f32x2{lo.y, hi.y}, f32x2{lo.z, hi.z}, tminf, tmaxf, tn) ? 1 : 0;
 }
 
 // ----------------------------------------------------------- primary rays ----
