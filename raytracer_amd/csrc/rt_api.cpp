@@ -64,6 +64,8 @@ struct DeviceGuard {  // makes the scene's device current for the duration of a 
 uint32_t g_inner_min = 16;
 // Samples of one pixel that make a unit of work (the sample range is cut into chunks of about this size).
 uint32_t g_chunk_spp = 64;
+// Fewest units of work a call is cut into (32 per lane of the chip).
+uint64_t g_target_units = 1u << 23;
 
 }  // namespace
 
@@ -499,7 +501,7 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
   // more of them.  Enough chunks to keep lanes busy (about g_chunk_spp samples each, at most 16),
   // more when the rectangle has few pixels, fewer when the partial sums would not fit in 4 GB.
   // The count depends on the request only.
-  const uint64_t kTargetLanes = 1u << 21;
+  const uint64_t kTargetLanes = g_target_units;
   uint64_t pixels = (uint64_t)tw * th;
   uint64_t want = std::max<uint64_t>(std::min<uint64_t>(16, spp / std::max<uint32_t>(1, g_chunk_spp)), (kTargetLanes + pixels - 1) / pixels);
   want = std::min<uint64_t>(want, std::max<uint64_t>(1, (4ull << 30) / (pixels * 24)));
@@ -624,6 +626,11 @@ int rt_debug_set(const char* name, double value) {
   if (!name) return fail(RT_ERR_INVALID, "rt_debug_set: name is null");
   if (std::strcmp(name, "inner_min") == 0) {
     g_inner_min = (uint32_t)value;
+    return RT_OK;
+  }
+  if (std::strcmp(name, "target_units") == 0) {
+    if (!(value >= 1.0 && value <= 1e12)) return fail(RT_ERR_INVALID, "rt_debug_set: target_units must be in 1 .. 1e12");
+    g_target_units = (uint64_t)value;
     return RT_OK;
   }
   if (std::strcmp(name, "chunk_spp") == 0) {
