@@ -213,9 +213,13 @@ int rt_render(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32
 int rt_render_device(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
                      const rt_rect* tile, double* rgb_sum_dev, void* stream, rt_render_stats* stats);
 
-/* Tuning knobs for experiments; not part of the stable interface.  Known names:
+/* Tuning knobs and test hooks; not part of the stable interface.  Known names:
  * "inner_min" (lanes of 64 that must want the inner-node block for a wave to run
- * it without counting the other blocks; it never changes results). */
+ * it without counting the other blocks), "chunk_spp" and "target_units" (how a
+ * call's sample range is cut into units of work) -- none of these changes which
+ * samples are rendered; "force_global_stack" (scenes created while it is 1 keep
+ * their traversal stacks in global memory, the path trees deeper than 35 levels
+ * take). */
 int rt_debug_set(const char* name, double value);
 
 /* `write_colour` (src/camera.rs:85-95) for n pixels: out is n x 3 bytes. Host only. */

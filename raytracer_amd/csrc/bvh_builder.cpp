@@ -14,6 +14,9 @@ const double kInf = std::numeric_limits<double>::infinity();
 const double kLeafCost = 1.0;         // src/bvh.rs:87
 const double kSplitCost = 1.0 / 8.0;  // src/bvh.rs:88
 const int kBuckets = 32;              // src/bvh.rs:89
+// Splitting stops at this level (the rest becomes one leaf): inputs such as spheres in geometric
+// progression would otherwise recurse once per sphere.  No tree of a realistic scene comes near it.
+const uint32_t kMaxBuildDepth = 64;
 
 inline Box empty_box() {  // AABB::new, src/aabb.rs:11-16
   return Box{{kInf, kInf, kInf}, {-kInf, -kInf, -kInf}};
@@ -202,7 +205,7 @@ struct Builder {
       }
     }
 
-    if (have && best_cost < kLeafCost * (double)n) {  // src/bvh.rs:124
+    if (have && best_cost < kLeafCost * (double)n && depth < kMaxBuildDepth) {  // src/bvh.rs:124
       // Stable partition keeps both sides in ascending sphere order; tmp[lo, hi) is this node's scratch.
       size_t nl = 0, nr = 0;
       for (size_t k = lo; k < hi; ++k) {

@@ -66,6 +66,8 @@ uint32_t g_inner_min = 16;
 uint32_t g_chunk_spp = 64;
 // Fewest units of work a call is cut into (32 per lane of the chip).
 uint64_t g_target_units = 1u << 23;
+// Test hook: scenes created while this is set keep their traversal stacks in global memory, as very deep trees must.
+bool g_force_global_stack = false;
 
 }  // namespace
 
@@ -245,11 +247,11 @@ int rt_scene_create_ex(const rt_sphere* spheres, size_t n, const rt_material* ma
 
   // LDS plan for one workgroup per CU: the per-lane stacks are mandatory; then, while they
   // fit, the top of the tree, the sphere records, the slots' shading data and the materials.
+  // A tree too deep for that keeps its stacks in global memory (allocated per call) and LDS holds scene data only.
   const uint32_t depth = tree_depth ? tree_depth : 1;
-  const size_t stack_bytes = (size_t)depth * kWorkgroup * 4;
   const size_t reserve = lds_fixed_bytes() + 64;
-  if (stack_bytes + reserve + 16 * 1024 > kLdsPerCu)
-    return fail(RT_ERR_LIMIT, "rt_scene_create: BVH depth " + std::to_string(depth) + " needs more traversal stack than LDS holds");
+  const bool stack_in_lds = depth <= max_depth && !g_force_global_stack;
+  const size_t stack_bytes = stack_in_lds ? (size_t)depth * kWorkgroup * 4 : 0;
   size_t room = kLdsPerCu - stack_bytes - reserve;
   const size_t node_bytes = n_dev_nodes * sizeof(DevNode), sph_bytes = n * sizeof(DevSphere);
   const size_t aux_bytes = n * sizeof(DevSphereAux), mat_bytes = nm * 32;
@@ -291,6 +293,7 @@ int rt_scene_create_ex(const rt_sphere* spheres, size_t n, const rt_material* ma
   sc->dev.n_aux_lds = n_aux_lds;
   sc->dev.n_materials_lds = n_mat_lds;
   sc->dev.stack_cap = depth;
+  sc->dev.stack_in_lds = stack_in_lds ? 1u : 0u;
   sc->dev.root = on_device ? tree.root : flat.root;
   sc->dev.bound = on_device ? tree.bound : flat.bound;
 
@@ -377,7 +380,15 @@ int rt_trace_batch(const rt_scene* sc, const double* org, const double* dir, siz
   RT_HIP(d_f.alloc(n));
   RT_HIP(hipMemcpy(d_org.p, org, n * 24, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(d_dir.p, dir, n * 24, hipMemcpyHostToDevice));
-  RT_HIP(launch_trace_batch(sc->dev, d_org.as<double>(), d_dir.as<double>(), n, t_min, t_max, d_prim.as<int32_t>(), d_t.as<double>(),
+  SceneDev dev = sc->dev;
+  DevBuf gstack;
+  if (!dev.stack_in_lds) {  // a tree too deep for LDS stacks: one column of global memory per thread of the launch
+    const size_t blocks = std::min<size_t>((n + kWorkgroup - 1) / kWorkgroup, (size_t)sc->num_cus);
+    dev.gstack_stride = (uint32_t)(blocks * kWorkgroup);
+    RT_HIP(gstack.alloc((size_t)dev.gstack_stride * dev.stack_cap * 4));
+    dev.gstack = gstack.as<uint32_t>();
+  }
+  RT_HIP(launch_trace_batch(dev, d_org.as<double>(), d_dir.as<double>(), n, t_min, t_max, d_prim.as<int32_t>(), d_t.as<double>(),
                             d_n.as<double>(), d_f.as<uint8_t>(), nullptr, sc->num_cus, nullptr));
   RT_HIP(hipDeviceSynchronize());
   RT_HIP(hipMemcpy(prim, d_prim.p, n * 4, hipMemcpyDeviceToHost));
@@ -537,7 +548,12 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
   P.inner_min = g_inner_min;
   if (const char* env = std::getenv("RT_INNER_MIN")) P.inner_min = (uint32_t)std::atoi(env);
 
-  DevBuf counters, partial;
+  DevBuf counters, partial, gstack;
+  if (!P.sc.stack_in_lds) {
+    P.sc.gstack_stride = (uint32_t)sc->num_cus * kWorkgroup;
+    RT_HIP(gstack.alloc((size_t)P.sc.gstack_stride * P.sc.stack_cap * 4));
+    P.sc.gstack = gstack.as<uint32_t>();
+  }
   RT_HIP(counters.alloc(kRenderCounters * 8));
   RT_HIP(hipMemsetAsync(counters.p, 0, kRenderCounters * 8, stream));
   P.counters = counters.as<unsigned long long>();
@@ -626,6 +642,10 @@ int rt_debug_set(const char* name, double value) {
   if (!name) return fail(RT_ERR_INVALID, "rt_debug_set: name is null");
   if (std::strcmp(name, "inner_min") == 0) {
     g_inner_min = (uint32_t)value;
+    return RT_OK;
+  }
+  if (std::strcmp(name, "force_global_stack") == 0) {
+    g_force_global_stack = value != 0.0;
     return RT_OK;
   }
   if (std::strcmp(name, "target_units") == 0) {

@@ -315,8 +315,9 @@ __device__ __forceinline__ void fetch_sphere(const TreeView& tv, uint32_t slot, 
 // replaces the current one only if strictly closer (Interval::surrounds,
 // src/ray.rs:35-37), spheres of a leaf are tested in stored order, and only two
 // different spheres hit at exactly the same distance could be told apart by
-// it.  `stack` is this lane's column of the LDS stack, entries `stride` words
-// apart; the tree is never deeper than its capacity.
+// it.  `stack` is this lane's column of the stack (in LDS, or in global memory for
+// trees too deep for LDS), entries `stride` words apart; the tree is never
+// deeper than its capacity.
 struct Trav {
   D3 o, d;
   RayBox q;
@@ -346,7 +347,8 @@ __device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D
 
 // The next node is already in a register when it is needed; the entry below it is
 // fetched from LDS behind the node test that follows.
-__device__ __forceinline__ void trav_pop(Trav& tr, lds_u32* stack, uint32_t stride) {
+template <class StackPtr>
+__device__ __forceinline__ void trav_pop(Trav& tr, StackPtr stack, uint32_t stride) {
   tr.cur = tr.tos;
   tr.tos = kRefDone;
   if (tr.sp != 0) {
@@ -354,15 +356,16 @@ __device__ __forceinline__ void trav_pop(Trav& tr, lds_u32* stack, uint32_t stri
     tr.tos = stack[tr.sp * stride];
   }
 }
-__device__ __forceinline__ void trav_push(Trav& tr, lds_u32* stack, uint32_t stride, uint32_t ref) {
+template <class StackPtr>
+__device__ __forceinline__ void trav_push(Trav& tr, StackPtr stack, uint32_t stride, uint32_t ref) {
   stack[tr.sp * stride] = tr.tos;
   ++tr.sp;
   tr.tos = ref;
 }
 
 // One inner node: test both children, descend into the first one hit.
-template <bool kAllLds>
-__device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, lds_u32* stack, uint32_t stride, float tminf) {
+template <bool kAllLds, class StackPtr>
+__device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride, float tminf) {
   f32x4 q3;
   bool h0, h1;
   float tn0 = 0.0f, tn1 = 0.0f;
@@ -392,8 +395,8 @@ __device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, ld
 
 // One leaf: Sphere::hit (src/sphere.rs:29-48) for each of its spheres.  The
 // direction has unit length, so the reference's a = |d|^2 is taken as 1.
-template <bool kAllLds>
-__device__ __forceinline__ void trav_leaf_step(Trav& tr, const TreeView& tv, lds_u32* stack, uint32_t stride, double t_min,
+template <bool kAllLds, class StackPtr>
+__device__ __forceinline__ void trav_leaf_step(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride, double t_min,
                                                uint32_t& n_tests) {
   const uint32_t first = tr.cur & 0x00ffffffu, count = (tr.cur >> 24) & 0x7fu;
   for (uint32_t k = 0; k < count; ++k) {
@@ -419,8 +422,8 @@ __device__ __forceinline__ void trav_leaf_step(Trav& tr, const TreeView& tv, lds
 }
 
 // Runs the query to completion (all lanes of the wave together).
-template <bool kAllLds>
-__device__ __forceinline__ void trav_run(Trav& tr, const TreeView& tv, lds_u32* stack, uint32_t stride, double t_min, uint32_t& n_steps,
+template <bool kAllLds, class StackPtr>
+__device__ __forceinline__ void trav_run(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride, double t_min, uint32_t& n_steps,
                                          uint32_t& n_tests) {
   const float tminf = f32_below(t_min);
   while (tr.cur != kRefDone) {

@@ -55,7 +55,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
 }
 
 // ------------------------------------------------------------ trace batch ----
-template <bool kAllLds>
+template <bool kAllLds, bool kGStack>
 __global__ __launch_bounds__(kWorkgroup) void trace_batch_kernel(SceneDev sc, const double* __restrict__ org, const double* __restrict__ dir,
                                                                  size_t n, double t_min, double t_max, int32_t* __restrict__ prim,
                                                                  double* __restrict__ t_out, double* __restrict__ normal,
@@ -63,14 +63,17 @@ __global__ __launch_bounds__(kWorkgroup) void trace_batch_kernel(SceneDev sc, co
   extern __shared__ float4 smem[];
   const LdsImage im = stage_scene(sc, nullptr, smem, kWorkgroup);
   const TreeView& tv = im.tv;
-  lds_u32* stack = im.stack_base + threadIdx.x;
+  const uint32_t gtid = blockIdx.x * kWorkgroup + threadIdx.x;
   for (size_t i = (size_t)blockIdx.x * kWorkgroup + threadIdx.x; i < n; i += (size_t)gridDim.x * kWorkgroup) {
     D3 o = d3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
     D3 d = normalize(d3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));  // Ray::new, src/ray.rs:16-23
     Trav tr;
     trav_begin(tr, tv, o, d, t_max);
     uint32_t n_steps = 0, n_tests = 0;
-    trav_run<kAllLds>(tr, tv, stack, kWorkgroup, t_min, n_steps, n_tests);
+    if constexpr (kGStack)
+      trav_run<kAllLds>(tr, tv, sc.gstack + gtid, sc.gstack_stride, t_min, n_steps, n_tests);
+    else
+      trav_run<kAllLds>(tr, tv, im.stack_base + threadIdx.x, kWorkgroup, t_min, n_steps, n_tests);
     if (tr.best >= 0) {
       Hit h = make_hit<kAllLds>(tv, tr.best, o, d, tr.t_best);
       prim[i] = (int32_t)h.prim;
@@ -200,13 +203,20 @@ __device__ __forceinline__ uint32_t count_lanes(bool p) {
 #define RTA_T1(k) \
   if (kProf) prof_cycles[k] += __builtin_amdgcn_s_memtime() - t0_;
 
-template <bool kAllLds, bool kProf>
+template <bool kAllLds, bool kProf, bool kGStack>
 __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  // 16 waves per CU: at most 128 VGPRs
   extern __shared__ float4 smem[];
   const LdsImage im = stage_scene(P.sc, &P.cam, smem, kWorkgroup);
   const TreeView& tv = im.tv;
   // The lane's stack column is recomputed where it is used (one add), not kept in a register.
-#define RTA_STACK (im.stack_base + threadIdx.x)
+  auto stack_of_lane = [&]() {
+    if constexpr (kGStack)
+      return P.sc.gstack + (blockIdx.x * kWorkgroup + threadIdx.x);
+    else
+      return im.stack_base + threadIdx.x;
+  };
+  const uint32_t stack_stride = kGStack ? P.sc.gstack_stride : kWorkgroup;
+#define RTA_STACK stack_of_lane()
   const uint32_t lane = threadIdx.x & 63u;
   const double t_min = 1e-3;  // src/camera.rs:102
   const float tminf = f32_below(t_min);
@@ -357,12 +367,12 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
         RTA_T0()
         if (!(tr.cur & kRefLeaf)) {
           RTA_PROF(BLK_INNER)
-          trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
+          trav_inner_step<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
           if (kProf) ++n_steps;
 #pragma unroll
           for (int k = 1; k < kInnerSteps; ++k) {  // most lanes that took a step want another one
             if (!(tr.cur & kRefLeaf)) {
-              trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
+              trav_inner_step<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
               if (kProf) ++n_steps;
             }
           }
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
         RTA_T0()
         if (!(tr.cur & kRefLeaf)) {
           RTA_PROF(BLK_INNER)
-          trav_inner_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, tminf);
+          trav_inner_step<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
           if (kProf) ++n_steps;
         }
         RTA_T1(BLK_INNER)
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
         if ((tr.cur & kRefLeaf) && tr.cur < kRefIdle) {
           RTA_PROF(BLK_LEAF)
           uint32_t tests = 0;
-          trav_leaf_step<kAllLds>(tr, tv, RTA_STACK, kWorkgroup, t_min, tests);
+          trav_leaf_step<kAllLds>(tr, tv, RTA_STACK, stack_stride, t_min, tests);
           if (kProf) n_tests += tests;
         }
         RTA_T1(BLK_LEAF)
@@ -492,7 +502,7 @@ size_t lds_node_bytes() { return kLdsNodeQuads * 16; }
 size_t lds_fixed_bytes() { return CAM_DOUBLES * 8; }
 size_t tree_lds_bytes(const SceneDev& sc) {
   return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * lds_node_bytes() + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
-         (size_t)sc.n_materials_lds * 32 + (size_t)sc.stack_cap * kWorkgroup * 4;
+         (size_t)sc.n_materials_lds * 32 + (sc.stack_in_lds ? (size_t)sc.stack_cap * kWorkgroup * 4 : 0);
 }
 
 static bool all_in_lds(const SceneDev& sc) {
@@ -508,7 +518,8 @@ hipError_t launch_trace_batch(const SceneDev& sc, const double* org, const doubl
                               double* t, double* normal, uint8_t* front, uint32_t* counts, int max_blocks, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   size_t lds = tree_lds_bytes(sc);
-  auto fn = all_in_lds(sc) ? trace_batch_kernel<true> : trace_batch_kernel<false>;
+  auto fn = sc.stack_in_lds ? (all_in_lds(sc) ? trace_batch_kernel<true, false> : trace_batch_kernel<false, false>)
+                            : (all_in_lds(sc) ? trace_batch_kernel<true, true> : trace_batch_kernel<false, true>);
   hipError_t e = allow_lds((const void*)fn, lds);
   if (e != hipSuccess) return e;
   size_t blocks = (n + kWorkgroup - 1) / kWorkgroup;
@@ -544,8 +555,9 @@ hipError_t launch_primary_rays(const CameraDev& cam, uint64_t seed, const uint32
 
 hipError_t launch_render(const RenderParams& P, int blocks, bool profile, hipStream_t stream) {
   size_t lds = tree_lds_bytes(P.sc);
-  auto fn = all_in_lds(P.sc) ? (profile ? render_kernel<true, true> : render_kernel<true, false>)
-                             : (profile ? render_kernel<false, true> : render_kernel<false, false>);
+  auto fn = all_in_lds(P.sc) ? (profile ? render_kernel<true, true, false> : render_kernel<true, false, false>)
+                             : (profile ? render_kernel<false, true, false> : render_kernel<false, false, false>);
+  if (!P.sc.stack_in_lds) fn = all_in_lds(P.sc) ? render_kernel<true, false, true> : render_kernel<false, false, true>;  // no profiling variant
   hipError_t e = allow_lds((const void*)fn, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kWorkgroup), lds, stream, P);

@@ -26,6 +26,9 @@ struct SceneDev {
   uint32_t n_materials;
   uint32_t n_nodes_lds, n_spheres_lds, n_aux_lds, n_materials_lds;
   uint32_t stack_cap;       // traversal stack entries per lane
+  uint32_t stack_in_lds;    // 1: the stacks live in LDS; 0: the tree is too deep, they live in gstack
+  uint32_t* gstack;         // global traversal stacks (set per launch): entry e of thread t at gstack[e * gstack_stride + t]
+  uint32_t gstack_stride;   // threads of the launch
   uint32_t root;            // ref of the root: inner node 0, a leaf ref, or 0xffffffff for an empty scene
   float bound;              // largest |coordinate| of any box plane in the tree
 };

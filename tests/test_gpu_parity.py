@@ -556,3 +556,35 @@ def test_device_built_tree_large_and_degenerate():
         if name != "same centre":
             assert np.array_equal(got["prim"], prim), name
         w.close()
+
+
+def test_traversal_stacks_in_global_memory(oracle, rtiow):
+    # Trees deeper than LDS can hold stacks for (35 levels; about 16 million spheres and up) keep the stacks in
+    # global memory.  The hook forces that path for an ordinary scene; everything must come out the same.
+    import ctypes as C
+
+    spheres, materials = rtiow
+    L = rt._lib.lib()
+    rt._lib.check(L.rt_debug_set(b"force_global_stack", C.c_double(1.0)))
+    try:
+        world = rt.BVH(spheres, materials)
+        big_s, big_m = rt.scene_field(3, 20000, 1.0 / 3.0, 1.0 / 3.0)
+        big = rt.BVH(big_s, big_m)
+    finally:
+        rt._lib.check(L.rt_debug_set(b"force_global_stack", C.c_double(0.0)))
+    ref = rt.BVH(spheres, materials)
+    assert world.info()["lds_bytes"] < ref.info()["lds_bytes"]  # no stacks in LDS
+    rng = np.random.default_rng(41)
+    org, d = _secondary_rays(spheres[1:], rng, 1 << 14)
+    a, b = world.trace_batch(org, d), ref.trace_batch(org, d)
+    assert np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["t"], b["t"]) and np.array_equal(a["normal"], b["normal"])
+    cam = rt.config_rtiow(image_width=96, samples_per_pixel=8, max_depth=50).camera()
+    got, st = cam.render_sum(world, seed=4)
+    want, st2 = cam.render_sum(ref, seed=4)
+    assert np.array_equal(got, want) and st["rays"] == st2["rays"]
+    org2, d2 = _secondary_rays(big_s[1:], rng, 1 << 14)
+    obig = _oracle_scene(oracle, big_s, big_m)
+    ties, rel_t, dn = compare_hits(big.trace_batch(org2, d2), obig.trace_batch(org2, d2))
+    assert ties <= 4
+    for w in (world, big, ref):
+        w.close()
