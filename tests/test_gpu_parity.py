@@ -588,3 +588,36 @@ def test_traversal_stacks_in_global_memory(oracle, rtiow):
     assert ties <= 4
     for w in (world, big, ref):
         w.close()
+
+
+def test_concurrent_calls_on_one_scene(world):
+    # a scene is immutable after creation: host threads may render and trace from it at the same time
+    import threading
+
+    cam = rt.config_rtiow(image_width=160, samples_per_pixel=16, max_depth=50).camera()
+    want, st = cam.render_sum(world, seed=21)
+    rng = np.random.default_rng(2)
+    org, d = _secondary_rays(world.spheres[1:], rng, 1 << 14)
+    want_hits = world.trace_batch(org, d)
+    results, errors = [None] * 6, []
+
+    def work(k):
+        try:
+            if k % 2 == 0:
+                results[k] = cam.render_sum(world, seed=21)[0]
+            else:
+                results[k] = world.trace_batch(org, d)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(6):
+        if k % 2 == 0:
+            assert np.array_equal(results[k], want)
+        else:
+            assert np.array_equal(results[k]["prim"], want_hits["prim"]) and np.array_equal(results[k]["t"], want_hits["t"])
