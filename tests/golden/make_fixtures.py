@@ -72,6 +72,12 @@ def main():
     img, stats = scene.render(small.record().view(orc.CONFIG_DTYPE), 12345, 0, 64, nthreads=os.cpu_count() or 1)
     np.savez_compressed(os.path.join(HERE, "image_64x36_64spp.npz"), rgb_sum=img, stats=stats, ppm_bytes=orc.quantise(img, 64))
 
+    # the same image converged: 4096 samples per pixel with the reference's own samplers (the rejection loops of
+    # src/vector.rs:16-47 on a sequential stream), to check the direct-map samplers of the GPU path against
+    high = rt.config_rtiow(image_width=64, samples_per_pixel=4096, max_depth=50)
+    conv, cstats = scene.render(high.record().view(orc.CONFIG_DTYPE), 99, 0, 4096, mode=orc.SAMPLER_REJECTION, nthreads=os.cpu_count() or 1)
+    np.savez_compressed(os.path.join(HERE, "image_64x36_4096spp_reference_samplers.npz"), rgb_mean=conv / 4096.0, stats=cstats)
+
     # the scene itself, so the fixtures are self-contained
     np.savez_compressed(os.path.join(HERE, "scene_rtiow_seed1.npz"), spheres=spheres, materials=materials)
     print("wrote fixtures to", HERE)
