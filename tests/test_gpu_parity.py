@@ -621,3 +621,25 @@ def test_concurrent_calls_on_one_scene(world):
             assert np.array_equal(results[k], want)
         else:
             assert np.array_equal(results[k]["prim"], want_hits["prim"]) and np.array_equal(results[k]["t"], want_hits["t"])
+
+
+def test_full_resolution_frame_properties(world):
+    # 3840 x 2160, the benchmark's frame, at a sample count the test can afford: properties that do not need the
+    # oracle.  A frame is the sum of its sample ranges and of its tiles (same paths, so also the same ray counts),
+    # and its mean radiance is that of the scene (the 64 x 36 converged fixture has 0.419).
+    cam = rt.config_rtiow(image_width=3840, samples_per_pixel=6, max_depth=50).camera()
+    h = cam.image_height
+    whole, st = cam.render_sum(world, seed=12345)
+    assert st["samples"] == 3840 * h * 6 and whole.shape == (h, 3840, 3)
+    parts = np.zeros_like(whole)
+    rays = 0
+    for s0, s1 in ((0, 2), (2, 6)):
+        for tile in ((0, 0, 1923, h), (1923, 0, 3840, 1001), (1923, 1001, 3840, h)):
+            _, stp = cam.render_sum(world, seed=12345, spp_begin=s0, spp_end=s1, tile=tile, rgb_sum=parts)
+            rays += stp["rays"]
+    assert rays == st["rays"]
+    assert np.abs(parts - whole).max() <= 1e-12 * np.abs(whole).max()
+    assert np.isfinite(whole).all() and (whole >= 0).all()
+    mean = whole.mean() / 6.0
+    assert abs(mean - 0.419) < 0.004
+    assert abs(st["rays"] / st["samples"] - 2.853) < 0.01  # mean path length of this scene and camera
