@@ -247,6 +247,7 @@ constexpr uint32_t kRefIdle = 0xfffffffdu;    // nothing left to do; every leaf 
 constexpr uint32_t kLdsNodeQuads = 7;
 
 typedef __attribute__((address_space(3))) f32x4 lds_float4;
+typedef __attribute__((address_space(3))) f32x2 lds_float2;
 typedef __attribute__((address_space(3))) f64x2 lds_double2;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
@@ -277,20 +278,20 @@ __device__ __forceinline__ void stage_node(lds_float4* lnodes, uint32_t i, f32x4
 }
 // Node i from LDS for a ray whose byte offsets into the node are off = (x, y, z copy to read).
 __device__ __forceinline__ void fetch_node_lds(const TreeView& tv, uint32_t i, uint32_t offx, uint32_t offy, uint32_t offz, f32x4& X, f32x4& Y,
-                                               f32x4& Z, f32x4& q3) {
+                                               f32x4& Z, f32x2& refs) {
   typedef __attribute__((address_space(3))) char lds_char;
   lds_char* base = (lds_char*)tv.lnodes;
   X = *(lds_float4*)(base + __umul24(i, kLdsNodeQuads * 16u) + offx);  // 24-bit multiply-add, full rate
   Y = *(lds_float4*)(base + __umul24(i, kLdsNodeQuads * 16u) + offy);
   Z = *(lds_float4*)(base + __umul24(i, kLdsNodeQuads * 16u) + offz);
-  q3 = *(lds_float4*)(base + __umul24(i, kLdsNodeQuads * 16u) + 96u);
+  refs = *(lds_float2*)(base + __umul24(i, kLdsNodeQuads * 16u) + 96u);  // only the two references: no dead destination registers
 }
-__device__ __forceinline__ void fetch_node_global(const TreeView& tv, uint32_t i, f32x4& q0, f32x4& q1, f32x4& q2, f32x4& q3) {
+__device__ __forceinline__ void fetch_node_global(const TreeView& tv, uint32_t i, f32x4& q0, f32x4& q1, f32x4& q2, f32x2& refs) {
   const f32x4* p = reinterpret_cast<const f32x4*>(tv.gnodes) + 4 * (size_t)i;
   q0 = p[0];
   q1 = p[1];
   q2 = p[2];
-  q3 = p[3];
+  refs = *reinterpret_cast<const f32x2*>(p + 3);
 }
 
 template <bool kAllLds>
@@ -366,7 +367,7 @@ __device__ __forceinline__ void trav_push(Trav& tr, StackPtr stack, uint32_t str
 // One inner node: test both children, descend into the first one hit.
 template <bool kAllLds, class StackPtr>
 __device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride, float tminf) {
-  f32x4 q3;
+  f32x2 q3;
   bool h0, h1;
   float tn0 = 0.0f, tn1 = 0.0f;
   if (kAllLds || tr.cur < tv.n_lds) {
@@ -391,6 +392,82 @@ __device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, St
   } else {
     trav_pop(tr, stack, stride);
   }
+}
+
+// Two inner-node steps with the second node's fetch issued before the first step's stack
+// bookkeeping, so that the bookkeeping runs while the fetch is in flight.  Same effect on the
+// traversal state as two calls of trav_inner_step (the second only if the cursor is still at
+// an inner node).
+struct NodeData {
+  f32x4 a, b, c;
+  f32x2 q3;  // the two child references
+  bool sorted;  // a, b, c are the direction-sorted LDS copies (near planes in .xy, far in .zw) rather than q0, q1, q2
+};
+template <bool kAllLds>
+__device__ __forceinline__ NodeData node_fetch(const Trav& tr, const TreeView& tv, uint32_t i) {
+  NodeData n;
+  if (kAllLds || i < tv.n_lds) {
+    fetch_node_lds(tv, i, tr.offx, tr.offy, tr.offz, n.a, n.b, n.c, n.q3);
+    n.sorted = true;
+  } else {
+    fetch_node_global(tv, i, n.a, n.b, n.c, n.q3);
+    n.sorted = false;
+  }
+  return n;
+}
+struct NodeChoice {
+  uint32_t next, far;
+  bool both, any;
+};
+template <bool kAllLds>
+__device__ __forceinline__ NodeChoice node_choose(const Trav& tr, const NodeData& n, float tminf) {
+  bool h0, h1;
+  float tn0 = 0.0f, tn1 = 0.0f;
+  if (kAllLds || n.sorted) {
+    h0 = box_test_sorted(tr.q, n.a.x, n.b.x, n.c.x, n.a.z, n.b.z, n.c.z, tminf, tr.tmaxf, tn0);
+    h1 = box_test_sorted(tr.q, n.a.y, n.b.y, n.c.y, n.a.w, n.b.w, n.c.w, tminf, tr.tmaxf, tn1);
+  } else {
+    h0 = box_test(tr.q, f32x2{n.a.x, n.a.y}, f32x2{n.b.x, n.b.y}, f32x2{n.c.x, n.c.y}, tminf, tr.tmaxf, tn0);
+    h1 = box_test(tr.q, f32x2{n.a.z, n.a.w}, f32x2{n.b.z, n.b.w}, f32x2{n.c.z, n.c.w}, tminf, tr.tmaxf, tn1);
+  }
+  const uint32_t ref0 = __float_as_uint(n.q3.x), ref1 = __float_as_uint(n.q3.y);
+  const bool swap = tn1 < tn0;
+  NodeChoice c;
+  c.both = h0 && h1;
+  c.any = h0 || h1;
+  c.far = swap ? ref0 : ref1;
+  c.next = c.both ? (swap ? ref1 : ref0) : (c.any ? (h0 ? ref0 : ref1) : tr.tos);
+  return c;
+}
+// The stack side of a step whose cursor move (to c.next) is done by the caller.
+template <class StackPtr>
+__device__ __forceinline__ void node_apply(Trav& tr, const NodeChoice& c, StackPtr stack, uint32_t stride) {
+  if (c.both) {
+    trav_push(tr, stack, stride, c.far);
+  } else if (!c.any) {  // c.next was the top of the stack: bring up the entry below it
+    tr.tos = kRefDone;
+    if (tr.sp != 0) {
+      --tr.sp;
+      tr.tos = stack[tr.sp * stride];
+    }
+  }
+}
+template <bool kAllLds, class StackPtr>
+__device__ __forceinline__ uint32_t trav_inner_pair(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride, float tminf) {
+  const NodeData na = node_fetch<kAllLds>(tr, tv, tr.cur);
+  const NodeChoice ca = node_choose<kAllLds>(tr, na, tminf);
+  const bool go = !(ca.next & kRefLeaf);
+  NodeData nb;
+  if (go) nb = node_fetch<kAllLds>(tr, tv, ca.next);
+  node_apply(tr, ca, stack, stride);
+  tr.cur = ca.next;
+  if (go) {
+    const NodeChoice cb = node_choose<kAllLds>(tr, nb, tminf);
+    node_apply(tr, cb, stack, stride);
+    tr.cur = cb.next;
+    return 2u;
+  }
+  return 1u;
 }
 
 // One leaf: Sphere::hit (src/sphere.rs:29-48) for each of its spheres.  The

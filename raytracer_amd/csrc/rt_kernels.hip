@@ -367,15 +367,8 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
         RTA_T0()
         if (!(tr.cur & kRefLeaf)) {
           RTA_PROF(BLK_INNER)
-          trav_inner_step<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
-          if (kProf) ++n_steps;
-#pragma unroll
-          for (int k = 1; k < kInnerSteps; ++k) {  // most lanes that took a step want another one
-            if (!(tr.cur & kRefLeaf)) {
-              trav_inner_step<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
-              if (kProf) ++n_steps;
-            }
-          }
+          const uint32_t steps = trav_inner_pair<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
+          if (kProf) n_steps += steps;
         }
         RTA_T1(BLK_INNER)
         n_inner = count_lanes(!(tr.cur & kRefLeaf));
