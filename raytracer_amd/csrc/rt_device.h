@@ -442,15 +442,19 @@ __device__ __forceinline__ NodeChoice node_choose(const Trav& tr, const NodeData
 // The stack side of a step whose cursor move (to c.next) is done by the caller.
 template <class StackPtr>
 __device__ __forceinline__ void node_apply(Trav& tr, const NodeChoice& c, StackPtr stack, uint32_t stride) {
-  if (c.both) {
-    trav_push(tr, stack, stride, c.far);
-  } else if (!c.any) {  // c.next was the top of the stack: bring up the entry below it
-    tr.tos = kRefDone;
+  // The store goes to the free slot above the stack's top in every lane; it only counts where
+  // sp then moves up (both children hit).  The stack has a slot to spare for it.
+  stack[tr.sp * stride] = tr.tos;
+  if (!c.both && !c.any) {  // c.next was the top of the stack: bring up the entry below it
+    uint32_t below = kRefDone;
     if (tr.sp != 0) {
       --tr.sp;
-      tr.tos = stack[tr.sp * stride];
+      below = stack[tr.sp * stride];
     }
+    tr.tos = below;
   }
+  tr.sp += c.both ? 1u : 0u;
+  tr.tos = c.both ? c.far : tr.tos;
 }
 template <bool kAllLds, class StackPtr>
 __device__ __forceinline__ uint32_t trav_inner_pair(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride, float tminf) {
