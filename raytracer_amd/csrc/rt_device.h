@@ -66,6 +66,22 @@ __device__ __forceinline__ double local_const(double c) {
   return c;
 }
 
+// Square root of a finite x >= 0 that is not huge or tiny enough to need rescaling (|x| within
+// 1e-280 .. 1e280, or 0): the reciprocal-square-root instruction refined by the same Goldschmidt
+// steps and residual corrections the compiler's sqrt uses, without its range checks.
+__device__ __forceinline__ double sqrt_plain(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  return x > 0.0 ? g : 0.0;  // rsq(0) is infinite
+}
+
 // sin and cos of 2*pi*u for u in [0,1): the argument is reduced exactly to a
 // quarter turn q and a remainder |f| <= 1/8 of a turn, then the classic
 // minimax polynomials for sin and cos on [-pi/4, pi/4] are evaluated
@@ -100,7 +116,7 @@ __device__ __forceinline__ void sincos_2pi(double u, double& s, double& c) {
 // (vector::random_unit, src/vector.rs:16-27).
 __device__ __forceinline__ D3 unit_from_uniforms(double u0, double u1) {
   double z = 1.0 - 2.0 * u0;
-  double rxy = sqrt(fmax(0.0, 1.0 - z * z));
+  double rxy = sqrt_plain(fmax(0.0, 1.0 - z * z));
   double s, c;
   sincos_2pi(u1, s, c);
   return d3(rxy * c, rxy * s, z);
@@ -108,7 +124,7 @@ __device__ __forceinline__ D3 unit_from_uniforms(double u0, double u1) {
 // Uniform point in the unit disk: r = sqrt(u0), phi = 2 pi u1
 // (vector::random_within_unit_disk, src/vector.rs:29-40).
 __device__ __forceinline__ void disk_from_uniforms(double u0, double u1, double& px, double& py) {
-  double r = sqrt(u0);
+  double r = sqrt_plain(u0);
   double s, c;
   sincos_2pi(u1, s, c);
   px = r * c;
@@ -489,7 +505,7 @@ __device__ __forceinline__ void trav_leaf_step(Trav& tr, const TreeView& tv, Sta
     double c = dot(oc, oc) - s1.y * s1.y;
     double disc = half_b * half_b - c;
     if (disc >= 0.0) {
-      double sq = sqrt(disc);
+      double sq = sqrt_plain(disc);
       double t = -half_b - sq;
       if (!(t_min < t && t < tr.t_best)) t = -half_b + sq;
       if (t_min < t && t < tr.t_best) {
@@ -566,7 +582,7 @@ __device__ __forceinline__ bool scatter(const TreeView& tv, uint32_t mat, D3 d, 
     attenuation = d3(1.0, 1.0, 1.0);
     double ratio = h.front ? m0.y : m0.x;  // ir^-1 entering, ir leaving (src/material.rs:52)
     double cos_theta = fmin(-dot(d, h.normal), 1.0);
-    double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+    double sin_theta = sqrt_plain(fmax(0.0, 1.0 - cos_theta * cos_theta));
     bool cannot_refract = ratio * sin_theta > 1.0;
     double x = 1.0 - cos_theta, x2 = x * x;
     double reflectance = m1.x + (1.0 - m1.x) * (x2 * x2 * x);  // Schlick, src/material.rs:45-50
@@ -574,7 +590,7 @@ __device__ __forceinline__ bool scatter(const TreeView& tv, uint32_t mat, D3 d, 
       dir = d - (2.0 * dot(d, h.normal)) * h.normal;  // vector::reflect, src/vector.rs:56-58
     } else {  // vector::refract, src/vector.rs:60-65
       D3 perp = ratio * (d + cos_theta * h.normal);
-      double par = -sqrt(fabs(1.0 - dot(perp, perp)));
+      double par = -sqrt_plain(fabs(1.0 - dot(perp, perp)));
       dir = perp + par * h.normal;
     }
   } else {
