@@ -298,7 +298,8 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
             tr.cur = kRefCamera;
           }
         }
-      } else {
+      }
+      if (block == BLK_CAMERA) {
         // The wave hands out the units of its current batch in order; when they run out it takes
         // the next batch from the global counter.  (Wave-uniform bookkeeping, done by all lanes.)
         const uint32_t n_need = count_lanes(tr.cur == kRefCamera && s >= s_last);
