@@ -393,6 +393,16 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
         pick = BLK_SHADE;
       }
       if (n_camera > most) pick = BLK_CAMERA;
+      if (pick > BLK_LEAF) {  // SHADE: the cold part runs it
+        block = pick;
+        break;
+      }
+      if (pick == BLK_CAMERA) {
+        block = pick;
+        break;
+      }
+      // uniform ifs in sequence rather than if/else: the compiler then merges each block's results
+      // into the lane state in place instead of copying the state around the pair
       if (pick == BLK_INNER) {
         RTA_T0()
         if (!(tr.cur & kRefLeaf)) {
@@ -401,7 +411,8 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           if (kProf) ++n_steps;
         }
         RTA_T1(BLK_INNER)
-      } else if (pick == BLK_LEAF) {
+      }
+      if (pick == BLK_LEAF) {
         RTA_T0()
         if ((tr.cur & kRefLeaf) && tr.cur < kRefIdle) {
           RTA_PROF(BLK_LEAF)
@@ -410,9 +421,6 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           if (kProf) n_tests += tests;
         }
         RTA_T1(BLK_LEAF)
-      } else {
-        block = pick;
-        break;
       }
     }
     if (finished) break;
