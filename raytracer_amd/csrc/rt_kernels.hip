@@ -272,25 +272,19 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
     {
       RTA_T0()
       if (block == BLK_SHADE) {
-        if (tr.cur == kRefDone) {
+        if (tr.cur == kRefDone && tr.best >= 0) {  // a ray that missed everything is finished by the camera block
           RTA_PROF(BLK_SHADE)
           ++n_rays;
           bool ended = true;
-          if (tr.best < 0) {  // sky, src/camera.rs:103-107
-            double a = (tr.d.y + 1.0) / 2.0;
-            D3 sky = d3((1.0 - a) + a * 0.5, (1.0 - a) + a * 0.7, (1.0 - a) + a * 1.0);
-            acc = acc + thr * sky;
-          } else {
-            const Hit h = make_hit<kAllLds>(tv, tr.best, tr.o, tr.d, tr.t_best);
-            double u0, u1;
-            philox_pair(P.seed_lo, P.seed_hi, RTA_J * P.cam.width + RTA_I, s, P.cam.max_depth - depth_left, DOM_SCATTER, u0, u1);
-            D3 att, nd;
-            if (scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd)) {  // None = absorbed, src/camera.rs:108-110
-              thr = thr * att;
-              if (--depth_left != 0) {  // depth exhausted: the path contributes nothing (src/camera.rs:99-101)
-                trav_begin(tr, tv, h.p, nd, __builtin_inf());  // HitRecord::ray, src/hit.rs:29-31
-                ended = false;
-              }
+          const Hit h = make_hit<kAllLds>(tv, tr.best, tr.o, tr.d, tr.t_best);
+          double u0, u1;
+          philox_pair(P.seed_lo, P.seed_hi, RTA_J * P.cam.width + RTA_I, s, P.cam.max_depth - depth_left, DOM_SCATTER, u0, u1);
+          D3 att, nd;
+          if (scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd)) {  // None = absorbed, src/camera.rs:108-110
+            thr = thr * att;
+            if (--depth_left != 0) {  // depth exhausted: the path contributes nothing (src/camera.rs:99-101)
+              trav_begin(tr, tv, h.p, nd, __builtin_inf());  // HitRecord::ray, src/hit.rs:29-31
+              ended = false;
             }
           }
           if (ended) {
@@ -302,6 +296,16 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
       if (block == BLK_CAMERA) {
         // The wave hands out the units of its current batch in order; when they run out it takes
         // the next batch from the global counter.  (Wave-uniform bookkeeping, done by all lanes.)
+        // A ray that left the scene adds the sky (src/camera.rs:103-107) and ends its path here, in the
+        // same block that starts the next one, instead of waiting for a shade round first.
+        if (tr.cur == kRefDone && tr.best < 0) {
+          ++n_rays;
+          double a = (tr.d.y + 1.0) / 2.0;
+          D3 sky = d3((1.0 - a) + a * 0.5, (1.0 - a) + a * 0.7, (1.0 - a) + a * 1.0);
+          acc = acc + thr * sky;
+          ++s;
+          tr.cur = kRefCamera;
+        }
         const uint32_t n_need = count_lanes(tr.cur == kRefCamera && s >= s_last);
         const uint32_t old_next = wave_next, old_avail = wave_end - wave_next, old_base = wave_base, old_origin = wave_origin;
         uint32_t new_first = 0;
@@ -376,8 +380,8 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
       }
       // Too few: run the block most lanes are waiting for.
       const uint32_t n_leaf = count_lanes((tr.cur & kRefLeaf) && tr.cur < kRefIdle);
-      const uint32_t n_shade = count_lanes(tr.cur == kRefDone);
-      const uint32_t n_camera = count_lanes(tr.cur == kRefCamera);
+      const uint32_t n_shade = count_lanes(tr.cur == kRefDone && tr.best >= 0);
+      const uint32_t n_camera = count_lanes(tr.cur == kRefCamera || (tr.cur == kRefDone && tr.best < 0));
       if ((n_inner | n_leaf | n_shade | n_camera) == 0u) {
         finished = true;
         break;
