@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
       }
       // uniform ifs in sequence rather than if/else: the compiler then merges each block's results
       // into the lane state in place instead of copying the state around the pair
-      if (pick == BLK_INNER) {
+      if (pick == BLK_INNER || n_inner >= P.both_min) {
         RTA_T0()
         if (!(tr.cur & kRefLeaf)) {
           RTA_PROF(BLK_INNER)
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
         }
         RTA_T1(BLK_INNER)
       }
-      if (pick == BLK_LEAF) {
+      if (pick == BLK_LEAF || n_leaf >= P.both_min) {
         RTA_T0()
         if ((tr.cur & kRefLeaf) && tr.cur < kRefIdle) {
           RTA_PROF(BLK_LEAF)
