@@ -61,9 +61,11 @@ struct DeviceGuard {  // makes the scene's device current for the duration of a 
 };
 
 // Lanes (of 64) that must want the inner-node block for a wave to run it without looking at the other blocks.
-uint32_t g_inner_min = 16;
+uint32_t g_inner_min = 8;
 // Lanes that must want the other traversal block (inner or leaf) for it to run in the same round as the one that is due.
 uint32_t g_both_min = 8;
+// Lanes waiting at leaves that make the leaf block run between inner-node rounds.
+uint32_t g_leaf_min = 10;
 // Samples of one pixel that make a unit of work (the sample range is cut into chunks of about this size).
 uint32_t g_chunk_spp = 64;
 // Fewest units of work a call is cut into (32 per lane of the chip).
@@ -549,6 +551,7 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
   P.direct = n_chunks == 1 ? 1u : 0u;
   P.inner_min = g_inner_min;
   P.both_min = g_both_min;
+  P.leaf_min = g_leaf_min;
   if (const char* env = std::getenv("RT_INNER_MIN")) P.inner_min = (uint32_t)std::atoi(env);
 
   DevBuf counters, partial, gstack;
@@ -645,6 +648,10 @@ int rt_debug_set(const char* name, double value) {
   if (!name) return fail(RT_ERR_INVALID, "rt_debug_set: name is null");
   if (std::strcmp(name, "inner_min") == 0) {
     g_inner_min = (uint32_t)value;
+    return RT_OK;
+  }
+  if (std::strcmp(name, "leaf_min") == 0) {
+    g_leaf_min = (uint32_t)value;
     return RT_OK;
   }
   if (std::strcmp(name, "both_min") == 0) {

@@ -376,6 +376,16 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           if (kProf) n_steps += steps;
         }
         RTA_T1(BLK_INNER)
+        if (count_lanes((tr.cur & kRefLeaf) && tr.cur < kRefIdle) >= P.leaf_min) {  // many lanes have reached leaves: test them now
+          RTA_T0()
+          if ((tr.cur & kRefLeaf) && tr.cur < kRefIdle) {
+            RTA_PROF(BLK_LEAF)
+            uint32_t tests = 0;
+            trav_leaf_step<kAllLds>(tr, tv, RTA_STACK, stack_stride, t_min, tests);
+            if (kProf) n_tests += tests;
+          }
+          RTA_T1(BLK_LEAF)
+        }
         n_inner = count_lanes(!(tr.cur & kRefLeaf));
       }
       // Too few: run the block most lanes are waiting for.

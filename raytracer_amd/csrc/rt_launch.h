@@ -52,6 +52,7 @@ struct RenderParams {
   uint32_t batch_chunks, batches_per_tile, n_batches;  // a wave takes batch_chunks chunks of one tile at a time from the global counter
   uint32_t direct;     // 1: out is the image and is added to; 0: out is the partial-sum buffer and is overwritten
   uint32_t inner_min;  // a wave runs the inner-node block while at least this many of its lanes want it
+  uint32_t leaf_min;   // inside a run of inner-node rounds the leaf block runs as soon as this many lanes wait at leaves
   uint32_t both_min;   // when a traversal block (inner or leaf) is due, the other one runs too if this many lanes want it
   double* out;
   unsigned long long* counters;  // see kRenderCounters
