@@ -365,18 +365,24 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
 
     bool finished = false;
     for (;;) {
-      // Inner-node rounds while enough lanes want them: the innermost loop, which only moves
-      // the cursor and the stack.
+      // Traversal rounds while enough lanes want them: the innermost loop, which only moves the
+      // cursor, the stack and the closest hit.  A round runs the inner-node block (two steps per
+      // lane) if inner_min lanes are at inner nodes and then the leaf block if leaf_min lanes are
+      // at leaves; it ends when neither is the case.
       uint32_t n_inner = count_lanes(!(tr.cur & kRefLeaf));
-      while (n_inner >= P.inner_min) {
-        RTA_T0()
-        if (!(tr.cur & kRefLeaf)) {
-          RTA_PROF(BLK_INNER)
-          const uint32_t steps = trav_inner_pair<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
-          if (kProf) n_steps += steps;
+      for (;;) {
+        bool ran = false;
+        if (n_inner >= P.inner_min) {
+          RTA_T0()
+          if (!(tr.cur & kRefLeaf)) {
+            RTA_PROF(BLK_INNER)
+            const uint32_t steps = trav_inner_pair<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
+            if (kProf) n_steps += steps;
+          }
+          RTA_T1(BLK_INNER)
+          ran = true;
         }
-        RTA_T1(BLK_INNER)
-        if (count_lanes((tr.cur & kRefLeaf) && tr.cur < kRefIdle) >= P.leaf_min) {  // many lanes have reached leaves: test them now
+        if (count_lanes((tr.cur & kRefLeaf) && tr.cur < kRefIdle) >= P.leaf_min) {
           RTA_T0()
           if ((tr.cur & kRefLeaf) && tr.cur < kRefIdle) {
             RTA_PROF(BLK_LEAF)
@@ -385,8 +391,10 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
             if (kProf) n_tests += tests;
           }
           RTA_T1(BLK_LEAF)
+          ran = true;
         }
         n_inner = count_lanes(!(tr.cur & kRefLeaf));
+        if (!ran) break;
       }
       // Too few: run the block most lanes are waiting for.
       const uint32_t n_leaf = count_lanes((tr.cur & kRefLeaf) && tr.cur < kRefIdle);
