@@ -61,7 +61,7 @@ struct DeviceGuard {  // makes the scene's device current for the duration of a 
 };
 
 // Lanes (of 64) that must want the inner-node block for a wave to run it without looking at the other blocks.
-uint32_t g_inner_min = 8;
+uint32_t g_inner_min = 10;
 // Lanes that must want the other traversal block (inner or leaf) for it to run in the same round as the one that is due.
 uint32_t g_both_min = 8;
 // Lanes waiting at leaves that make the leaf block run between inner-node rounds.

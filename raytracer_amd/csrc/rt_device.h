@@ -236,12 +236,42 @@ __device__ __forceinline__ bool box_test(const RayBox& q, f32x2 bx, f32x2 by, f3
   float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tmaxf));
   return tn <= tf;
 }
-// One box given by the planes the ray meets first (nx, ny, nz) and last (fx, fy, fz) on each axis.
-__device__ __forceinline__ bool box_test_sorted(const RayBox& q, float nx, float ny, float nz, float fx, float fy, float fz, float tminf,
-                                                float tmaxf, float& tn) {
-  tn = fmaxf(fmaxf(fmaf(nx, q.rx, q.nx.x), fmaf(ny, q.ry, q.ny.x)), fmaxf(fmaf(nz, q.rz, q.nz.x), tminf));
-  float tf = fminf(fminf(fmaf(fx, q.rx, q.nx.y), fmaf(fy, q.ry, q.ny.y)), fminf(fmaf(fz, q.rz, q.nz.y), tmaxf));
-  return tn <= tf;
+// min/max as the bare instructions: fminf/fmaxf pass an operand that was not computed in sight of
+// the compiler (the running far limit) through a quieting max(x, x) first.  A NaN operand (0 * inf on an axis the ray does not
+// move along) is dropped in favour of the other operands, which is the conservative answer.
+__device__ __forceinline__ float max_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float min_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// Both boxes of a node at once, from the direction-sorted planes (entry planes of box 0 and 1 in
+// .xy, exit planes in .zw).  Scalar multiply-adds: the packed two-wide form measured slower here.
+__device__ __forceinline__ void box_pair_sorted(const RayBox& q, f32x4 X, f32x4 Y, f32x4 Z, float tminf, float tmaxf, float& tn0, float& tn1,
+                                                bool& h0, bool& h1) {
+  const f32x2 nx = {fmaf(X.x, q.rx, q.nx.x), fmaf(X.y, q.rx, q.nx.x)}, fx = {fmaf(X.z, q.rx, q.nx.y), fmaf(X.w, q.rx, q.nx.y)};
+  const f32x2 ny = {fmaf(Y.x, q.ry, q.ny.x), fmaf(Y.y, q.ry, q.ny.x)}, fy = {fmaf(Y.z, q.ry, q.ny.y), fmaf(Y.w, q.ry, q.ny.y)};
+  const f32x2 nz = {fmaf(Z.x, q.rz, q.nz.x), fmaf(Z.y, q.rz, q.nz.x)}, fz = {fmaf(Z.z, q.rz, q.nz.y), fmaf(Z.w, q.rz, q.nz.y)};
+  tn0 = max3_raw(nx.x, ny.x, max_raw(nz.x, tminf));
+  tn1 = max3_raw(nx.y, ny.y, max_raw(nz.y, tminf));
+  const float tf0 = min3_raw(fx.x, fy.x, min_raw(fz.x, tmaxf));
+  const float tf1 = min3_raw(fx.y, fy.y, min_raw(fz.y, tmaxf));
+  h0 = tn0 <= tf0;
+  h1 = tn1 <= tf1;
 }
 
 // ------------------------------------------------------------- traversal ----
@@ -389,8 +419,7 @@ __device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, St
   if (kAllLds || tr.cur < tv.n_lds) {
     f32x4 X, Y, Z;
     fetch_node_lds(tv, tr.cur, tr.offx, tr.offy, tr.offz, X, Y, Z, q3);
-    h0 = box_test_sorted(tr.q, X.x, Y.x, Z.x, X.z, Y.z, Z.z, tminf, tr.tmaxf, tn0);
-    h1 = box_test_sorted(tr.q, X.y, Y.y, Z.y, X.w, Y.w, Z.w, tminf, tr.tmaxf, tn1);
+    box_pair_sorted(tr.q, X, Y, Z, tminf, tr.tmaxf, tn0, tn1, h0, h1);
   } else {
     f32x4 q0, q1, q2;
     fetch_node_global(tv, tr.cur, q0, q1, q2, q3);
@@ -440,8 +469,7 @@ __device__ __forceinline__ NodeChoice node_choose(const Trav& tr, const NodeData
   bool h0, h1;
   float tn0 = 0.0f, tn1 = 0.0f;
   if (kAllLds || n.sorted) {
-    h0 = box_test_sorted(tr.q, n.a.x, n.b.x, n.c.x, n.a.z, n.b.z, n.c.z, tminf, tr.tmaxf, tn0);
-    h1 = box_test_sorted(tr.q, n.a.y, n.b.y, n.c.y, n.a.w, n.b.w, n.c.w, tminf, tr.tmaxf, tn1);
+    box_pair_sorted(tr.q, n.a, n.b, n.c, tminf, tr.tmaxf, tn0, tn1, h0, h1);
   } else {
     h0 = box_test(tr.q, f32x2{n.a.x, n.a.y}, f32x2{n.b.x, n.b.y}, f32x2{n.c.x, n.c.y}, tminf, tr.tmaxf, tn0);
     h1 = box_test(tr.q, f32x2{n.a.z, n.a.w}, f32x2{n.b.z, n.b.w}, f32x2{n.c.z, n.c.w}, tminf, tr.tmaxf, tn1);
