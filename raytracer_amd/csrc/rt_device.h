@@ -396,12 +396,11 @@ __device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D
 // fetched from LDS behind the node test that follows.
 template <class StackPtr>
 __device__ __forceinline__ void trav_pop(Trav& tr, StackPtr stack, uint32_t stride) {
+  // With nothing below the top (sp == 0) the top is kRefDone, the traversal ends with this pop and
+  // what is read into the top is never looked at: no need to tell that case apart.
   tr.cur = tr.tos;
-  tr.tos = kRefDone;
-  if (tr.sp != 0) {
-    --tr.sp;
-    tr.tos = stack[tr.sp * stride];
-  }
+  tr.sp = __builtin_elementwise_sub_sat(tr.sp, 1u);
+  tr.tos = stack[tr.sp * stride];
 }
 template <class StackPtr>
 __device__ __forceinline__ void trav_push(Trav& tr, StackPtr stack, uint32_t stride, uint32_t ref) {
@@ -489,13 +488,9 @@ __device__ __forceinline__ void node_apply(Trav& tr, const NodeChoice& c, StackP
   // The store goes to the free slot above the stack's top in every lane; it only counts where
   // sp then moves up (both children hit).  The stack has a slot to spare for it.
   stack[tr.sp * stride] = tr.tos;
-  if (!c.both && !c.any) {  // c.next was the top of the stack: bring up the entry below it
-    uint32_t below = kRefDone;
-    if (tr.sp != 0) {
-      --tr.sp;
-      below = stack[tr.sp * stride];
-    }
-    tr.tos = below;
+  if (!c.both && !c.any) {  // c.next was the top of the stack: bring up the entry below it (see trav_pop for sp == 0)
+    tr.sp = __builtin_elementwise_sub_sat(tr.sp, 1u);
+    tr.tos = stack[tr.sp * stride];
   }
   tr.sp += c.both ? 1u : 0u;
   tr.tos = c.both ? c.far : tr.tos;
