@@ -205,8 +205,18 @@ def main():
             "hbm_GBs_measured": traffic["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 if traffic else None,
             "hbm_peak_GBs": HBM_PEAK_GBS,
             "note": "the whole scene (nodes, spheres, materials: 93 KB) lives in LDS, so neither HBM nor MFMA binds; "
-                    "the kernel is bound by vector-ALU issue with about 55-68 % of the lanes active per code block",
+                    "the kernel is bound by vector-ALU issue: the vector units issue all the time (see issue), "
+                    "with about 60 % of the lanes active per instruction",
         }
+        if traffic and "issue" in traffic:  # counter profile of the same workload: how busy the vector units are
+            issue = traffic["issue"]
+            out["roofline"]["issue"] = {
+                "valu_wave_instructions_per_launch": issue["valu_wave_instructions_per_launch"],
+                "simd_cycles_per_valu_instruction": issue["simd_cycles_per_valu_instruction"],
+                "mean_active_lanes_per_valu_instruction": issue["mean_active_lanes_per_valu_instruction"],
+                "measured_cycles_per_instruction_alone": "4.0-4.5 (fma, min/max, compare, select, f64), 2.5 (32-bit add, mul, xor, mov)",
+                "source": "profiles/r01_hbm_traffic.json, profiles/r01_valu_rate.txt",
+            }
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -167,17 +167,17 @@ __global__ __launch_bounds__(256) void primary_rays_kernel(CameraDev cam, uint32
 // samples in index order, so the sums do not depend on scheduling.
 //
 // Every lane is a small state machine that wants exactly one of four code
-// blocks next: CAMERA (start the next sample), INNER (one inner BVH node:
-// test both child boxes), LEAF (the spheres of one leaf) or SHADE (closest hit
-// known: sky or scatter, then the next ray or the end of the path).  Path and
-// traversal lengths differ from lane to lane, so instead of running every
-// lane's traversal to completion before shading, the wave counts with ballots
-// how many lanes want each block and runs one block per iteration: INNER
-// while at least `inner_min` lanes want it, otherwise the block most lanes are
-// waiting for.  Which block runs when never changes a lane's own sequence of
-// operations, so results do not depend on the policy.
+// blocks next: CAMERA (finish a ray that left the scene, start the next sample),
+// INNER (inner BVH nodes: test both child boxes), LEAF (the spheres of one leaf)
+// or SHADE (closest hit known: scatter, then the next ray or the end of the
+// path).  Path and traversal lengths differ from lane to lane, so instead of
+// running every lane's traversal to completion before shading, the wave counts
+// with ballots how many lanes want each block: traversal rounds (INNER if
+// `inner_min` lanes want it, then LEAF if `leaf_min` lanes want it) repeat while
+// either runs; otherwise the block most lanes are waiting for runs once.  Which
+// block runs when never changes a lane's own sequence of operations, so results
+// do not depend on the policy.
 enum { BLK_CAMERA = 0, BLK_INNER = 1, BLK_LEAF = 2, BLK_SHADE = 3 };
-constexpr int kInnerSteps = 2;  // inner-node steps a lane may take per scheduling round
 
 // Lanes of the wave for which p holds, as a 32-bit scalar (the barrier keeps the
 // compiler from carrying the count around as a 64-bit value).

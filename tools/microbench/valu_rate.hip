@@ -48,6 +48,17 @@ __global__ __launch_bounds__(1024) void rate_kernel(float* out, float a, float b
       if (kOp == 23) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x[k]) : "v"(a));
       if (kOp == 24) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(x[k]) : "v"(a), "v"(b));
       if (kOp == 25) asm volatile("v_cndmask_b32 %0, 0, %1, vcc" : "+v"(x[k]) : "v"(a));
+      if (kOp == 26) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "+v"(d[k]) : "v"(a), "v"(b) : "vcc");
+      if (kOp == 27) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
+      if (kOp == 28) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
+      if (kOp == 29) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(x[k]));
+      if (kOp == 30) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(d[k]) : "v"(a));
+      if (kOp == 31) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x[k]) : "v"(da));
+      if (kOp == 32) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(d[k]) : "v"(a));
+      if (kOp == 34) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
+      if (kOp == 35) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
+      if (kOp == 36) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
+      if (kOp == 37) asm volatile("v_mov_b64 %0, %1" : "=v"(d[k]) : "v"(da));
       if (kOp == 15) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pa));
     }
   }
@@ -99,6 +110,17 @@ int main() {
   run<21>("v_cmp+v_cndmask (2 instr)", out, cus);
   run<22>("v_cmp_lt_f32_e64 sgpr", out, cus);
   run<23>("v_lshl_add_u32", out, cus);
+  run<26>("v_mad_u64_u32", out, cus);
+  run<27>("v_xor_b32", out, cus);
+  run<28>("v_and_b32", out, cus);
+  run<29>("v_lshlrev_b32", out, cus);
+  run<36>("v_sub_u32", out, cus);
+  run<30>("v_cvt_f64_u32", out, cus);
+  run<31>("v_cvt_f32_f64", out, cus);
+  run<32>("v_ldexp_f64", out, cus);
+  run<34>("v_add_f32", out, cus);
+  run<35>("v_mul_f32", out, cus);
+  run<37>("v_mov_b64", out, cus);
   run<8>("v_mad_u32_u24", out, cus);
   run<9>("v_mul_lo_u32", out, cus);
   run<10>("v_mul_hi_u32", out, cus);
