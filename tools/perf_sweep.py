@@ -17,12 +17,20 @@ ap.add_argument("values", nargs="+", type=float)
 ap.add_argument("--spp", type=int, default=100)
 ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--config", default=None, help="c3, c4 or c5 of tools/run_configs.py instead of the reference scene (--width and --spp still apply)")
 a = ap.parse_args()
 
 L = rt._lib.lib()
-spheres, materials = rt.scene_rtiow(1)
+if a.config:
+    from run_configs import CONFIGS
+
+    n, pl, pm, fz, _, _, depth, seed = CONFIGS[a.config]
+    spheres, materials = rt.scene_field(seed, n, pl, pm, fz)
+    cfg = rt.config_field(n, a.width, a.spp, depth)
+else:
+    spheres, materials = rt.scene_rtiow(1)
+    cfg = rt.config_rtiow(a.width, a.spp, 50)
 world = rt.BVH(spheres, materials)
-cfg = rt.config_rtiow(a.width, a.spp, 50)
 cam = cfg.camera()
 frame = torch.zeros((cam.image_height, a.width, 3), dtype=torch.float64, device="cuda")
 best = {}
