@@ -69,7 +69,7 @@ uint32_t g_leaf_min = 10;
 // Samples of one pixel that make a unit of work (the sample range is cut into chunks of about this size).
 uint32_t g_chunk_spp = 64;
 // Fewest units of work a call is cut into (32 per lane of the chip).
-uint64_t g_target_units = 1u << 23;
+uint64_t g_target_units = 1u << 25;
 // Test hook: scenes created while this is set keep their traversal stacks in global memory, as very deep trees must.
 bool g_force_global_stack = false;
 
