@@ -217,7 +217,7 @@ int rt_render_device(const rt_scene* scene, const rt_config* cfg, uint64_t seed,
  * "inner_min" (lanes of 64 that must want the inner-node block for a wave to run
  * it without counting the other blocks), "leaf_min" (lanes waiting at leaves that make the leaf block run between
  * inner-node rounds), "both_min" (when the inner-node or the leaf
- * block is due, the other of the two runs as well if this many lanes want it), "chunk_spp" and "target_units" (how a
+ * block is due, the other of the two runs as well if this many lanes want it), "chunk_spp", "target_units" and "batches_per_wave" (how a
  * call's sample range is cut into units of work) -- none of these changes which
  * samples are rendered; "force_global_stack" (scenes created while it is 1 keep
  * their traversal stacks in global memory, the path trees deeper than 35 levels

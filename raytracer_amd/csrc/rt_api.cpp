@@ -70,6 +70,7 @@ uint32_t g_leaf_min = 10;
 uint32_t g_chunk_spp = 64;
 // Fewest units of work a call is cut into (32 per lane of the chip).
 uint64_t g_target_units = 1u << 25;
+uint64_t g_batches_per_wave = 32;
 // Test hook: scenes created while this is set keep their traversal stacks in global memory, as very deep trees must.
 bool g_force_global_stack = false;
 
@@ -543,9 +544,9 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
   if (P.cam.width > 0xffffu || P.cam.height > 0xffffu) return fail(RT_ERR_LIMIT, "rt_render: images larger than 65535 pixels on a side are not supported");
   P.n_units = (uint32_t)(n_items * 64);
   // A wave takes some chunks of one tile at a time: all of them when there are many tiles per wave,
-  // fewer when there are not, so that every wave gets about 16 batches.
+  // fewer when there are not, so that every wave gets about g_batches_per_wave batches.
   const uint64_t n_waves = (uint64_t)sc->num_cus * (kWorkgroup / 64);
-  P.batch_chunks = (uint32_t)std::min<uint64_t>(n_chunks, std::max<uint64_t>(1, n_items / (16 * n_waves)));
+  P.batch_chunks = (uint32_t)std::min<uint64_t>(n_chunks, std::max<uint64_t>(1, n_items / (g_batches_per_wave * n_waves)));
   P.batches_per_tile = (n_chunks + P.batch_chunks - 1) / P.batch_chunks;
   P.n_batches = P.n_tiles * P.batches_per_tile;
   P.direct = n_chunks == 1 ? 1u : 0u;
@@ -652,6 +653,10 @@ int rt_debug_set(const char* name, double value) {
   }
   if (std::strcmp(name, "leaf_min") == 0) {
     g_leaf_min = (uint32_t)value;
+    return RT_OK;
+  }
+  if (std::strcmp(name, "batches_per_wave") == 0) {
+    g_batches_per_wave = std::max<uint64_t>(1, (uint64_t)value);
     return RT_OK;
   }
   if (std::strcmp(name, "both_min") == 0) {
