@@ -301,6 +301,13 @@ int rt_scene_create_ex(const rt_sphere* spheres, size_t n, const rt_material* ma
   sc->dev.stack_in_lds = stack_in_lds ? 1u : 0u;
   sc->dev.root = on_device ? tree.root : flat.root;
   sc->dev.bound = on_device ? tree.bound : flat.bound;
+  bool single = true;  // the device builder makes one-sphere leaves only
+  if (!on_device) {
+    auto one = [](uint32_t ref) { return !(ref & kRefLeaf) || ref == kRefNone || ((ref >> 24) & 0x7fu) == 1u; };
+    single = one(flat.root);
+    for (const DevNode& nd : flat.nodes) single = single && one(nd.ref0) && one(nd.ref1);
+  }
+  sc->dev.single_leaves = single ? 1u : 0u;
 
   sc->info.n_spheres = n;
   sc->info.n_nodes = on_device ? 2 * n - 1 : sc->host.nodes.size();

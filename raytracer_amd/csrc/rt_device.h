@@ -309,6 +309,7 @@ struct TreeView {
   uint32_t n_lds, n_sph_lds, n_aux_lds, n_mat_lds;
   uint32_t root;
   float bound;
+  bool single_leaves;  // every leaf holds exactly one sphere
 };
 
 // Writes node i (global layout q0..q3) into its LDS slot.
@@ -515,27 +516,41 @@ __device__ __forceinline__ uint32_t trav_inner_pair(Trav& tr, const TreeView& tv
 
 // One leaf: Sphere::hit (src/sphere.rs:29-48) for each of its spheres.  The
 // direction has unit length, so the reference's a = |d|^2 is taken as 1.
+// Sphere::hit (src/sphere.rs:29-48) for the sphere in `slot`.  The direction has unit length, so
+// the reference's a = |d|^2 is taken as 1.
+template <bool kAllLds>
+__device__ __forceinline__ void sphere_test(Trav& tr, const TreeView& tv, uint32_t slot, double t_min) {
+  f64x2 s0, s1;
+  fetch_sphere<kAllLds>(tv, slot, s0, s1);
+  D3 oc = d3(tr.o.x - s0.x, tr.o.y - s0.y, tr.o.z - s1.x);
+  double half_b = dot(oc, tr.d);
+  double c = dot(oc, oc) - s1.y * s1.y;
+  double disc = half_b * half_b - c;
+  if (disc >= 0.0) {
+    double sq = sqrt_plain(disc);
+    double t = -half_b - sq;
+    if (!(t_min < t && t < tr.t_best)) t = -half_b + sq;
+    if (t_min < t && t < tr.t_best) {
+      tr.t_best = t;
+      tr.best = (int)slot;
+      tr.tmaxf = f32_above(t);
+    }
+  }
+}
+// One leaf: each of its spheres in stored order.  Trees whose leaves all hold one sphere (what
+// both builders make of spheres that do not coincide) take the branch without the loop.
 template <bool kAllLds, class StackPtr>
 __device__ __forceinline__ void trav_leaf_step(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride, double t_min,
                                                uint32_t& n_tests) {
-  const uint32_t first = tr.cur & 0x00ffffffu, count = (tr.cur >> 24) & 0x7fu;
-  for (uint32_t k = 0; k < count; ++k) {
-    f64x2 s0, s1;
-    fetch_sphere<kAllLds>(tv, first + k, s0, s1);
+  const uint32_t first = tr.cur & 0x00ffffffu;
+  if (tv.single_leaves) {
     ++n_tests;
-    D3 oc = d3(tr.o.x - s0.x, tr.o.y - s0.y, tr.o.z - s1.x);
-    double half_b = dot(oc, tr.d);
-    double c = dot(oc, oc) - s1.y * s1.y;
-    double disc = half_b * half_b - c;
-    if (disc >= 0.0) {
-      double sq = sqrt_plain(disc);
-      double t = -half_b - sq;
-      if (!(t_min < t && t < tr.t_best)) t = -half_b + sq;
-      if (t_min < t && t < tr.t_best) {
-        tr.t_best = t;
-        tr.best = (int)(first + k);
-        tr.tmaxf = f32_above(t);
-      }
+    sphere_test<kAllLds>(tr, tv, first, t_min);
+  } else {
+    const uint32_t count = (tr.cur >> 24) & 0x7fu;
+    for (uint32_t k = 0; k < count; ++k) {
+      ++n_tests;
+      sphere_test<kAllLds>(tr, tv, first + k, t_min);
     }
   }
   trav_pop(tr, stack, stride);

@@ -49,6 +49,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
   im.tv.n_mat_lds = sc.n_materials_lds;
   im.tv.root = sc.root;
   im.tv.bound = sc.bound;
+  im.tv.single_leaves = sc.single_leaves != 0u;
   im.cam.p = lcam;
   im.stack_base = stack_base;
   return im;

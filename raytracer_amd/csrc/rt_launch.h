@@ -30,6 +30,7 @@ struct SceneDev {
   uint32_t* gstack;         // global traversal stacks (set per launch): entry e of thread t at gstack[e * gstack_stride + t]
   uint32_t gstack_stride;   // threads of the launch
   uint32_t root;            // ref of the root: inner node 0, a leaf ref, or 0xffffffff for an empty scene
+  uint32_t single_leaves;   // 1: every leaf holds exactly one sphere (the leaf test then needs no loop)
   float bound;              // largest |coordinate| of any box plane in the tree
 };
 
