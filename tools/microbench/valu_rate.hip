@@ -59,6 +59,12 @@ __global__ __launch_bounds__(1024) void rate_kernel(float* out, float a, float b
       if (kOp == 35) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
       if (kOp == 36) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
       if (kOp == 37) asm volatile("v_mov_b64 %0, %1" : "=v"(d[k]) : "v"(da));
+      if (kOp == 40) { if (k & 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[k]) : "v"(a), "v"(b)); else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x[k]) : "v"(a), "v"(b)); }
+      if (kOp == 41) { if (k & 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]" : "+v"(p[k]) : "v"(pa), "v"(pb)); else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x[k]) : "v"(a), "v"(b)); }
+      if (kOp == 42) { if (k & 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[k]) : "v"(a), "v"(b)); else asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[k]) : "v"(a)); }
+      if (kOp == 43) { if (k & 1) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[k]) : "v"(da), "v"(db)); else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x[k]) : "v"(a), "v"(b)); }
+      if (kOp == 44) { if (k & 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]" : "+v"(p[k]) : "v"(pa), "v"(pb)); else asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(x[k]) : "v"(p[k^1].x), "v"(p[k^1].y), "v"(b)); }
+      if (kOp == 45) { if (k & 1) asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %3, %3, %1, %2" : "+v"(p[k].x), "+v"(p[k].y) : "v"(a), "v"(b)); else asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(x[k]) : "v"(p[k^1].x), "v"(p[k^1].y), "v"(b)); }
       if (kOp == 15) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pa));
     }
   }
@@ -121,6 +127,12 @@ int main() {
   run<34>("v_add_f32", out, cus);
   run<35>("v_mul_f32", out, cus);
   run<37>("v_mov_b64", out, cus);
+  run<40>("mix fma_f32 / max3", out, cus);
+  run<41>("mix pk_fma / max3", out, cus);
+  run<42>("mix fma_f32 / add_u32", out, cus);
+  run<43>("mix fma_f64 / max3", out, cus);
+  run<44>("pk_fma -> dependent max3", out, cus);
+  run<45>("2 fma -> dependent max3 (3 instr per 2 slots)", out, cus);
   run<8>("v_mad_u32_u24", out, cus);
   run<9>("v_mul_lo_u32", out, cus);
   run<10>("v_mul_hi_u32", out, cus);
