@@ -313,8 +313,18 @@ struct TreeView {
 };
 
 // Writes node i (global layout q0..q3) into its LDS slot.
+// kScaled (trees that are in LDS as a whole): references to inner nodes are stored as the byte
+// offset of the node in the LDS copy, so that following one needs no multiplication.
+template <bool kScaled>
 __device__ __forceinline__ void stage_node(lds_float4* lnodes, uint32_t i, f32x4 q0, f32x4 q1, f32x4 q2, f32x4 q3) {
   lds_float4* p = lnodes + kLdsNodeQuads * i;
+  if (kScaled) {
+    uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
+    if (!(r0 & kRefLeaf)) r0 *= kLdsNodeQuads * 16u;
+    if (!(r1 & kRefLeaf)) r1 *= kLdsNodeQuads * 16u;
+    q3.x = __uint_as_float(r0);
+    q3.y = __uint_as_float(r1);
+  }
   p[0] = f32x4{q0.x, q0.z, q0.y, q0.w};
   p[1] = f32x4{q0.y, q0.w, q0.x, q0.z};
   p[2] = f32x4{q1.x, q1.z, q1.y, q1.w};
@@ -324,14 +334,16 @@ __device__ __forceinline__ void stage_node(lds_float4* lnodes, uint32_t i, f32x4
   p[6] = q3;
 }
 // Node i from LDS for a ray whose byte offsets into the node are off = (x, y, z copy to read).
+template <bool kScaled>
 __device__ __forceinline__ void fetch_node_lds(const TreeView& tv, uint32_t i, uint32_t offx, uint32_t offy, uint32_t offz, f32x4& X, f32x4& Y,
                                                f32x4& Z, f32x2& refs) {
   typedef __attribute__((address_space(3))) char lds_char;
   lds_char* base = (lds_char*)tv.lnodes;
-  X = *(lds_float4*)(base + __umul24(i, kLdsNodeQuads * 16u) + offx);  // 24-bit multiply-add, full rate
-  Y = *(lds_float4*)(base + __umul24(i, kLdsNodeQuads * 16u) + offy);
-  Z = *(lds_float4*)(base + __umul24(i, kLdsNodeQuads * 16u) + offz);
-  refs = *(lds_float2*)(base + __umul24(i, kLdsNodeQuads * 16u) + 96u);  // only the two references: no dead destination registers
+  const uint32_t at = kScaled ? i : __umul24(i, kLdsNodeQuads * 16u);
+  X = *(lds_float4*)(base + at + offx);
+  Y = *(lds_float4*)(base + at + offy);
+  Z = *(lds_float4*)(base + at + offz);
+  refs = *(lds_float2*)(base + at + 96u);  // only the two references: no dead destination registers
 }
 __device__ __forceinline__ void fetch_node_global(const TreeView& tv, uint32_t i, f32x4& q0, f32x4& q1, f32x4& q2, f32x2& refs) {
   const f32x4* p = reinterpret_cast<const f32x4*>(tv.gnodes) + 4 * (size_t)i;
@@ -418,7 +430,7 @@ __device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, St
   float tn0 = 0.0f, tn1 = 0.0f;
   if (kAllLds || tr.cur < tv.n_lds) {
     f32x4 X, Y, Z;
-    fetch_node_lds(tv, tr.cur, tr.offx, tr.offy, tr.offz, X, Y, Z, q3);
+    fetch_node_lds<kAllLds>(tv, tr.cur, tr.offx, tr.offy, tr.offz, X, Y, Z, q3);
     box_pair_sorted(tr.q, X, Y, Z, tminf, tr.tmaxf, tn0, tn1, h0, h1);
   } else {
     f32x4 q0, q1, q2;
@@ -452,7 +464,7 @@ template <bool kAllLds>
 __device__ __forceinline__ NodeData node_fetch(const Trav& tr, const TreeView& tv, uint32_t i) {
   NodeData n;
   if (kAllLds || i < tv.n_lds) {
-    fetch_node_lds(tv, i, tr.offx, tr.offy, tr.offz, n.a, n.b, n.c, n.q3);
+    fetch_node_lds<kAllLds>(tv, i, tr.offx, tr.offy, tr.offz, n.a, n.b, n.c, n.q3);
     n.sorted = true;
   } else {
     fetch_node_global(tv, i, n.a, n.b, n.c, n.q3);

@@ -13,6 +13,7 @@ struct LdsImage {
   lds_u32* stack_base;
 };
 
+template <bool kAllLds>
 __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const CameraDev* cam, float4* smem, uint32_t wg) {
   lds_double* lcam = (lds_double*)smem;
   lds_float4* lnodes = (lds_float4*)(lcam + CAM_DOUBLES);
@@ -29,7 +30,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
     const double* src = k < 3 ? cam->center : k < 6 ? cam->pixel00 : k < 9 ? cam->du : k < 12 ? cam->dv : k < 15 ? cam->disk_u : cam->disk_v;
     lcam[k] = src[k % 3];
   }
-  for (uint32_t i = threadIdx.x; i < sc.n_nodes_lds; i += wg) stage_node(lnodes, i, gn[4 * i], gn[4 * i + 1], gn[4 * i + 2], gn[4 * i + 3]);
+  for (uint32_t i = threadIdx.x; i < sc.n_nodes_lds; i += wg) stage_node<kAllLds>(lnodes, i, gn[4 * i], gn[4 * i + 1], gn[4 * i + 2], gn[4 * i + 3]);
   for (uint32_t i = threadIdx.x; i < 2 * sc.n_spheres_lds; i += wg) lsph[i] = gs[i];
   for (uint32_t i = threadIdx.x; i < sc.n_aux_lds; i += wg) laux[i] = ga[i];
   for (uint32_t i = threadIdx.x; i < 2 * sc.n_materials_lds; i += wg) lmat[i] = gm[i];
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(kWorkgroup) void trace_batch_kernel(SceneDev sc, co
                                                                  double* __restrict__ t_out, double* __restrict__ normal,
                                                                  uint8_t* __restrict__ front, uint32_t* __restrict__ counts) {
   extern __shared__ float4 smem[];
-  const LdsImage im = stage_scene(sc, nullptr, smem, kWorkgroup);
+  const LdsImage im = stage_scene<kAllLds>(sc, nullptr, smem, kWorkgroup);
   const TreeView& tv = im.tv;
   const uint32_t gtid = blockIdx.x * kWorkgroup + threadIdx.x;
   for (size_t i = (size_t)blockIdx.x * kWorkgroup + threadIdx.x; i < n; i += (size_t)gridDim.x * kWorkgroup) {
@@ -207,7 +208,7 @@ __device__ __forceinline__ uint32_t count_lanes(bool p) {
 template <bool kAllLds, bool kProf, bool kGStack>
 __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  // 16 waves per CU: at most 128 VGPRs
   extern __shared__ float4 smem[];
-  const LdsImage im = stage_scene(P.sc, &P.cam, smem, kWorkgroup);
+  const LdsImage im = stage_scene<kAllLds>(P.sc, &P.cam, smem, kWorkgroup);
   const TreeView& tv = im.tv;
   // The lane's stack column is recomputed where it is used (one add), not kept in a register.
   auto stack_of_lane = [&]() {
