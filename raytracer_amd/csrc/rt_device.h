@@ -384,7 +384,7 @@ struct Trav {
   double t_best;
   float tmaxf;
   uint32_t offx, offy, offz;  // byte offset, inside a node staged in LDS, of the copy of each axis to read
-  uint32_t cur, sp;
+  uint32_t cur, sp;  // sp: bytes of stack in use below the top entry (see stack_slot)
   uint32_t tos;  // the top of the stack lives here; `sp` entries below it are in LDS
   int best;
 };
@@ -406,19 +406,27 @@ __device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D
 }
 
 // The next node is already in a register when it is needed; the entry below it is
-// fetched from LDS behind the node test that follows.
+// fetched from LDS behind the node test that follows.  `sp` counts in bytes (entries times the
+// distance between a lane's entries), so that a slot's address is one add away.
+__device__ __forceinline__ lds_u32* stack_slot(lds_u32* stack, uint32_t byte_offset) {
+  typedef __attribute__((address_space(3))) char lds_char;
+  return (lds_u32*)((lds_char*)stack + byte_offset);
+}
+__device__ __forceinline__ uint32_t* stack_slot(uint32_t* stack, uint32_t byte_offset) {
+  return (uint32_t*)((char*)stack + byte_offset);
+}
 template <class StackPtr>
 __device__ __forceinline__ void trav_pop(Trav& tr, StackPtr stack, uint32_t stride) {
   // With nothing below the top (sp == 0) the top is kRefDone, the traversal ends with this pop and
   // what is read into the top is never looked at: no need to tell that case apart.
   tr.cur = tr.tos;
-  tr.sp = __builtin_elementwise_sub_sat(tr.sp, 1u);
-  tr.tos = stack[tr.sp * stride];
+  tr.sp = __builtin_elementwise_sub_sat(tr.sp, 4u * stride);
+  tr.tos = *stack_slot(stack, tr.sp);
 }
 template <class StackPtr>
 __device__ __forceinline__ void trav_push(Trav& tr, StackPtr stack, uint32_t stride, uint32_t ref) {
-  stack[tr.sp * stride] = tr.tos;
-  ++tr.sp;
+  *stack_slot(stack, tr.sp) = tr.tos;
+  tr.sp += 4u * stride;
   tr.tos = ref;
 }
 
@@ -500,12 +508,12 @@ template <class StackPtr>
 __device__ __forceinline__ void node_apply(Trav& tr, const NodeChoice& c, StackPtr stack, uint32_t stride) {
   // The store goes to the free slot above the stack's top in every lane; it only counts where
   // sp then moves up (both children hit).  The stack has a slot to spare for it.
-  stack[tr.sp * stride] = tr.tos;
+  *stack_slot(stack, tr.sp) = tr.tos;
   if (!c.both && !c.any) {  // c.next was the top of the stack: bring up the entry below it (see trav_pop for sp == 0)
-    tr.sp = __builtin_elementwise_sub_sat(tr.sp, 1u);
-    tr.tos = stack[tr.sp * stride];
+    tr.sp = __builtin_elementwise_sub_sat(tr.sp, 4u * stride);
+    tr.tos = *stack_slot(stack, tr.sp);
   }
-  tr.sp += c.both ? 1u : 0u;
+  tr.sp += c.both ? 4u * stride : 0u;
   tr.tos = c.both ? c.far : tr.tos;
 }
 template <bool kAllLds, class StackPtr>
