@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--partition", choices=["samples", "tiles"], default="samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true", help="set up the process group and run the collectives even with one rank (a rehearsal of the N > 1 path on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -104,7 +105,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    distributed = world_size > 1
+    distributed = world_size > 1 or args.force_distributed
     if distributed:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -131,6 +132,8 @@ def main():
         torch.cuda.synchronize()  # torch's stream and the library's are not ordered with each other
         if weak:
             render_sample_split(render, frame, 0, total_spp, rank, world_size)
+            if args.force_distributed and world_size == 1:
+                dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)  # the collective of the N > 1 path, on one rank
         else:
             render_tile_split(render, w, h, 0, total_spp, rank, world_size)
 
