@@ -55,7 +55,6 @@ __device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b
 __device__ __forceinline__ D3 operator*(double s, D3 a) { return {s * a.x, s * a.y, s * a.z}; }
 __device__ __forceinline__ D3 operator*(D3 a, D3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 __device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ D3 normalize(D3 a) { return rsqrt(dot(a, a)) * a; }
 
 // A double constant that is materialised where it is used (two scalar moves).
 // Without this the compiler hoists the polynomial coefficients below out of
@@ -81,6 +80,16 @@ __device__ __forceinline__ double sqrt_plain(double x) {
   g = fma(d, h, g);
   return x > 0.0 ? g : 0.0;  // rsq(0) is infinite
 }
+
+// 1/sqrt(x) for a finite x > 0 that is not tiny or huge: the reciprocal-square-root instruction and
+// the refinement step the compiler's rsqrt uses, without its check for zero and infinite results.
+__device__ __forceinline__ double rsqrt_plain(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(y * x), y, 1.0);
+  return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+// A direction of the path: never the zero vector (scatter replaces a degenerate one, the camera looks somewhere).
+__device__ __forceinline__ D3 normalize(D3 a) { return rsqrt_plain(dot(a, a)) * a; }
 
 // sin and cos of 2*pi*u for u in [0,1): the argument is reduced exactly to a
 // quarter turn q and a remainder |f| <= 1/8 of a turn, then the classic
