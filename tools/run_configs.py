@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--only", default="c1,c3,c4,c5")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--builder", choices=["host", "device"], default="host")
+    ap.add_argument("--rooflines", action="store_true",
+                    help="also run the CPU oracle on a 160-pixel-wide, 2-spp sample of each configuration for the reference's node visits and sphere "
+                         "tests per ray, and price the measured ray rate against the vector-ALU and HBM ceilings")
     args = ap.parse_args()
     import torch
 
@@ -55,7 +58,26 @@ def main():
         st = cam.render_device(world, frame.data_ptr(), seed=12345)
         torch.cuda.synchronize()
         info = world.info()
+        extra = {}
+        if args.rooflines:
+            from oracle import oracle as orc
+
+            oscene = orc.Scene(spheres.view(orc.SPHERE_DTYPE), materials.view(orc.MATERIAL_DTYPE))
+            small = cfg.image_width(160).samples_per_pixel(2)
+            _, ost = oscene.render(small.record().view(orc.CONFIG_DTYPE), 12345, 0, 2, nthreads=min(16, os.cpu_count() or 1))
+            o_rays, o_visits, o_tests = (float(x) for x in ost)
+            v_bar, p_bar = o_visits / o_rays, o_tests / o_rays
+            rate = st["rays"] / (st["kernel_ms"] * 1e-3)
+            flops = 25.0 * v_bar + 28.0 * p_bar + 60.0  # per ray: slab tests, sphere tests, hit record + scatter + spawn
+            nbytes = 32.0 * v_bar + 32.0 * p_bar + 32.0  # per ray: 32 B per node visit (a 64-byte node holds two), f64 sphere, material
+            extra = {
+                "oracle_node_visits_per_ray": v_bar, "oracle_sphere_tests_per_ray": p_bar, "flops_per_ray": flops, "bytes_per_ray": nbytes,
+                "achieved_TFLOPs": rate * flops / 1e12, "frac_of_fp32_vector_peak_157.3": rate * flops / 1e12 / 157.3,
+                "achieved_algorithmic_GBs": rate * nbytes / 1e9, "frac_of_hbm_8000": rate * nbytes / 1e9 / 8000.0,
+                "binding": "vector ALU (tree in LDS)" if info["n_nodes_in_lds"] == info["n_device_nodes"] else "dependent node fetches out of L1/L2 (latency and load issue); the algorithmic bytes exceed what HBM could deliver only if they came from HBM, and they do not",
+            }
         print(json.dumps({
+            **extra,
             "config": name, "spheres": len(spheres), "width": width, "height": cam.image_height, "spp": spp, "depth": depth,
             "scene_gen_s": t1 - t0, "bvh_build_upload_s": t2 - t1, "builder": args.builder, "depth_levels": info["depth"], "build_ms": info["build_ms"], "device_nodes": info["n_device_nodes"],
             "nodes_in_lds": info["n_nodes_in_lds"], "device_bytes": info["device_bytes"], "render_ms": st["kernel_ms"], "launches": st["launches"],
