@@ -221,7 +221,9 @@ int rt_render_device(const rt_scene* scene, const rt_config* cfg, uint64_t seed,
  * call's sample range is cut into units of work) -- none of these changes which
  * samples are rendered; "force_global_stack" (scenes created while it is 1 keep
  * their traversal stacks in global memory, the path trees deeper than 35 levels
- * take). */
+ * take).  With RT_PROFILE_BLOCKS set in the environment, rt_render* runs the
+ * instrumented variant of the render kernel and prints, per code block, runs,
+ * mean active lanes and cycles to stderr (slower; results unchanged). */
 int rt_debug_set(const char* name, double value);
 
 /* `write_colour` (src/camera.rs:85-95) for n pixels: out is n x 3 bytes. Host only. */

@@ -560,7 +560,6 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
   P.inner_min = g_inner_min;
   P.both_min = g_both_min;
   P.leaf_min = g_leaf_min;
-  if (const char* env = std::getenv("RT_INNER_MIN")) P.inner_min = (uint32_t)std::atoi(env);
 
   DevBuf counters, partial, gstack;
   if (!P.sc.stack_in_lds) {
