@@ -236,6 +236,9 @@ __device__ __forceinline__ float f32_above(double v) {  // smallest f32 >= v
   float f = (float)v;
   return ((double)f < v) ? nextafterf(f, __builtin_inff()) : f;
 }
+// Some f32 >= v for a finite v > 0 well inside the f32 range: the nearest f32 moved one step up, without
+// looking at which way the conversion rounded (at most two steps above v instead of at most one).
+__device__ __forceinline__ float f32_beyond(double v) { return __uint_as_float(__float_as_uint((float)v) + 1u); }
 // One box given as (lo, hi) pairs per axis: does the ray cross it within [tminf, tmaxf]?
 __device__ __forceinline__ bool box_test(const RayBox& q, f32x2 bx, f32x2 by, f32x2 bz, float tminf, float tmaxf, float& tn) {
   f32x2 tx = f32x2{fmaf(bx.x, q.rx, q.cx.x), fmaf(bx.y, q.rx, q.cx.y)};
@@ -562,7 +565,7 @@ __device__ __forceinline__ void sphere_test(Trav& tr, const TreeView& tv, uint32
     if (t_min < t && t < tr.t_best) {
       tr.t_best = t;
       tr.best = (int)slot;
-      tr.tmaxf = f32_above(t);
+      tr.tmaxf = f32_beyond(t);
     }
   }
 }
