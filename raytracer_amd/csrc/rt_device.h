@@ -91,6 +91,23 @@ __device__ __forceinline__ double rsqrt_plain(double x) {
 // A direction of the path: never the zero vector (scatter replaces a degenerate one, the camera looks somewhere).
 __device__ __forceinline__ D3 normalize(D3 a) { return rsqrt_plain(dot(a, a)) * a; }
 
+// The same for the sphere test's discriminant (x >= 0): a zero is lifted to 2^-1000 instead of being
+// singled out afterwards, so an exactly tangent ray gets a root 1e-150 off, which no sum with a
+// distance of the scene's scale can see.
+__device__ __forceinline__ double sqrt_disc(double x) {
+  double xx;
+  asm("v_max_f64 %0, %1, %2" : "=v"(xx) : "v"(x), "v"(0x1p-1000));
+  const double y = __builtin_amdgcn_rsq(xx);
+  double g = xx * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, xx);
+  g = fma(d, h, g);
+  d = fma(-g, g, xx);
+  return fma(d, h, g);
+}
+
 // sin and cos of 2*pi*u for u in [0,1): the argument is reduced exactly to a
 // quarter turn q and a remainder |f| <= 1/8 of a turn, then the classic
 // minimax polynomials for sin and cos on [-pi/4, pi/4] are evaluated
@@ -559,7 +576,7 @@ __device__ __forceinline__ void sphere_test(Trav& tr, const TreeView& tv, uint32
   double c = dot(oc, oc) - s1.y * s1.y;
   double disc = half_b * half_b - c;
   if (disc >= 0.0) {
-    double sq = sqrt_plain(disc);
+    double sq = sqrt_disc(disc);
     double t = -half_b - sq;
     if (!(t_min < t && t < tr.t_best)) t = -half_b + sq;
     if (t_min < t && t < tr.t_best) {
