@@ -588,11 +588,13 @@ __device__ __forceinline__ void sphere_test(Trav& tr, const TreeView& tv, uint32
 }
 // One leaf: each of its spheres in stored order.  Trees whose leaves all hold one sphere (what
 // both builders make of spheres that do not coincide) take the branch without the loop.
-template <bool kAllLds, class StackPtr>
+// kSingle: the caller knows at compile time that the tree is of that kind (the loop is then not even
+// compiled in, which also spares the copies that merging the two forms costs).
+template <bool kAllLds, bool kSingle = false, class StackPtr>
 __device__ __forceinline__ void trav_leaf_step(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride, double t_min,
                                                uint32_t& n_tests) {
   const uint32_t first = tr.cur & 0x00ffffffu;
-  if (tv.single_leaves) {
+  if (kSingle || tv.single_leaves) {
     ++n_tests;
     sphere_test<kAllLds>(tr, tv, first, t_min);
   } else {

@@ -205,7 +205,7 @@ __device__ __forceinline__ uint32_t count_lanes(bool p) {
 #define RTA_T1(k) \
   if (kProf) prof_cycles[k] += __builtin_amdgcn_s_memtime() - t0_;
 
-template <bool kAllLds, bool kProf, bool kGStack>
+template <bool kAllLds, bool kProf, bool kGStack, bool kSingle>
 __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  // 16 waves per CU: at most 128 VGPRs
   extern __shared__ float4 smem[];
   const LdsImage im = stage_scene<kAllLds>(P.sc, &P.cam, smem, kWorkgroup);
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           if ((tr.cur & kRefLeaf) && tr.cur < kRefIdle) {
             RTA_PROF(BLK_LEAF)
             uint32_t tests = 0;
-            trav_leaf_step<kAllLds>(tr, tv, RTA_STACK, stack_stride, t_min, tests);
+            trav_leaf_step<kAllLds, kSingle>(tr, tv, RTA_STACK, stack_stride, t_min, tests);
             if (kProf) n_tests += tests;
           }
           RTA_T1(BLK_LEAF)
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
         if ((tr.cur & kRefLeaf) && tr.cur < kRefIdle) {
           RTA_PROF(BLK_LEAF)
           uint32_t tests = 0;
-          trav_leaf_step<kAllLds>(tr, tv, RTA_STACK, stack_stride, t_min, tests);
+          trav_leaf_step<kAllLds, kSingle>(tr, tv, RTA_STACK, stack_stride, t_min, tests);
           if (kProf) n_tests += tests;
         }
         RTA_T1(BLK_LEAF)
@@ -579,11 +579,23 @@ hipError_t launch_primary_rays(const CameraDev& cam, uint64_t seed, const uint32
   return hipGetLastError();
 }
 
+// The variant for the scene: tree wholly in LDS or not, stacks in LDS or in global memory, leaves of one
+// sphere each or not; the instrumented form exists for one-sphere leaves and LDS stacks only.
+template <bool kAllLds, bool kGStack>
+static void (*pick_render(bool single, bool profile))(RenderParams) {
+  if constexpr (!kGStack) {
+    if (profile && single) return render_kernel<kAllLds, true, false, true>;
+  }
+  return single ? render_kernel<kAllLds, false, kGStack, true> : render_kernel<kAllLds, false, kGStack, false>;
+}
 hipError_t launch_render(const RenderParams& P, int blocks, bool profile, hipStream_t stream) {
   size_t lds = tree_lds_bytes(P.sc);
-  auto fn = all_in_lds(P.sc) ? (profile ? render_kernel<true, true, false> : render_kernel<true, false, false>)
-                             : (profile ? render_kernel<false, true, false> : render_kernel<false, false, false>);
-  if (!P.sc.stack_in_lds) fn = all_in_lds(P.sc) ? render_kernel<true, false, true> : render_kernel<false, false, true>;  // no profiling variant
+  const bool single = P.sc.single_leaves != 0u;
+  void (*fn)(RenderParams);
+  if (P.sc.stack_in_lds)
+    fn = all_in_lds(P.sc) ? pick_render<true, false>(single, profile) : pick_render<false, false>(single, profile);
+  else
+    fn = all_in_lds(P.sc) ? pick_render<true, true>(single, profile) : pick_render<false, true>(single, profile);
   hipError_t e = allow_lds((const void*)fn, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kWorkgroup), lds, stream, P);
