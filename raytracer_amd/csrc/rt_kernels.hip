@@ -189,6 +189,12 @@ __device__ __forceinline__ uint32_t count_lanes(bool p) {
   return n;
 }
 
+__device__ __forceinline__ uint32_t count_mask(unsigned long long m) {
+  uint32_t n = (uint32_t)__builtin_popcountll(m);
+  asm volatile("" : "+s"(n));
+  return n;
+}
+
 // kProf: also count, per code block, how often it ran and with how many active lanes.
 #define RTA_PROF(k)                                              \
   if (kProf) {                                                    \
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           ++s;
           tr.cur = kRefCamera;
         }
-        const uint32_t n_need = count_lanes(tr.cur == kRefCamera && s >= s_last);
+        const uint32_t n_need = count_mask(__ballot(tr.cur == kRefCamera) & __ballot(s >= s_last));
         const uint32_t old_next = wave_next, old_avail = wave_end - wave_next, old_base = wave_base, old_origin = wave_origin;
         uint32_t new_first = 0;
         if (n_need > old_avail) {
@@ -400,8 +406,11 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
       }
       // Too few: run the block most lanes are waiting for.
       const uint32_t n_leaf = count_lanes((tr.cur & kRefLeaf) && tr.cur < kRefIdle);
-      const uint32_t n_shade = count_lanes(tr.cur == kRefDone && tr.best >= 0);
-      const uint32_t n_camera = count_lanes(tr.cur == kRefCamera || (tr.cur == kRefDone && tr.best < 0));
+      // (ballots of plain compares, combined as masks on the scalar side: a compound condition would be
+      // built per lane first)
+      const unsigned long long m_done = __ballot(tr.cur == kRefDone), m_hit = __ballot(tr.best >= 0);
+      const uint32_t n_shade = count_mask(m_done & m_hit);
+      const uint32_t n_camera = count_mask(__ballot(tr.cur == kRefCamera) | (m_done & ~m_hit));
       if ((n_inner | n_leaf | n_shade | n_camera) == 0u) {
         finished = true;
         break;
