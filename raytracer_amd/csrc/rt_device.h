@@ -577,8 +577,10 @@ __device__ __forceinline__ void sphere_test(Trav& tr, const TreeView& tv, uint32
   double disc = half_b * half_b - c;
   if (disc >= 0.0) {
     double sq = sqrt_disc(disc);
+    // The near root if it lies beyond t_min, else the far one (src/sphere.rs:38-44 takes the first of the two
+    // inside the interval; a near root at or beyond t_best leaves nothing for the far root, which is later still).
     double t = -half_b - sq;
-    if (!(t_min < t && t < tr.t_best)) t = -half_b + sq;
+    if (!(t_min < t)) t = -half_b + sq;
     if (t_min < t && t < tr.t_best) {
       tr.t_best = t;
       tr.best = (int)slot;
