@@ -590,6 +590,27 @@ def test_traversal_stacks_in_global_memory(oracle, rtiow):
         w.close()
 
 
+def test_frame_does_not_depend_on_scheduling(world):
+    # Which code block a wave runs when, and how units of work are batched, never changes a lane's own sequence of
+    # operations: the frame must come out bit for bit the same under any setting of the scheduling knobs.
+    import ctypes as C
+
+    L = rt._lib.lib()
+    cam = rt.config_rtiow(image_width=120, samples_per_pixel=24, max_depth=50).camera()
+    want, st = cam.render_sum(world, seed=77)
+    defaults = {b"inner_min": 10, b"leaf_min": 10, b"both_min": 8, b"batches_per_wave": 32}
+    try:
+        for knobs in [{b"inner_min": 1, b"leaf_min": 1, b"both_min": 1}, {b"inner_min": 64, b"leaf_min": 64, b"both_min": 64},
+                      {b"inner_min": 20, b"leaf_min": 3}, {b"batches_per_wave": 1}, {b"batches_per_wave": 1000, b"both_min": 33}]:
+            for k, v in {**defaults, **knobs}.items():
+                rt._lib.check(L.rt_debug_set(k, C.c_double(v)))
+            got, st2 = cam.render_sum(world, seed=77)
+            assert np.array_equal(got, want) and st2["rays"] == st["rays"], knobs
+    finally:
+        for k, v in defaults.items():
+            rt._lib.check(L.rt_debug_set(k, C.c_double(v)))
+
+
 def test_concurrent_calls_on_one_scene(world):
     # a scene is immutable after creation: host threads may render and trace from it at the same time
     import threading
