@@ -55,6 +55,9 @@ def main():
         cam = cfg.camera()
         frame = torch.zeros((cam.image_height, width, 3), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
+        cam.render_device(world, frame.data_ptr(), seed=1, spp_begin=0, spp_end=1)  # warm: code object, clocks
+        frame.zero_()
+        torch.cuda.synchronize()
         st = cam.render_device(world, frame.data_ptr(), seed=12345)
         torch.cuda.synchronize()
         info = world.info()
