@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X vector FP32 peak
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector FP64 peak
 HBM_PEAK_GBS = 8000.0
 
 
@@ -40,12 +41,23 @@ def flops_per_ray(v, p):
     return 25.0 * v + 28.0 * p + 60.0
 
 
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may use.  On a shared GPU host os.cpu_count() is the
+    whole machine; the share of one GPU's job is what the scheduler exports in OMP_NUM_THREADS (or the affinity mask)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        share = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        share = 0
+    return max(1, min(n, share) if share > 0 else n)
+
+
 def cpu_baseline(spheres, materials, seconds_target=15.0):
     from oracle import oracle as orc
 
     import raytracer_amd as rt
 
-    threads = max(1, min(16, os.cpu_count() or 1))
+    threads = host_threads()
     scene = orc.Scene(spheres.view(orc.SPHERE_DTYPE), materials.view(orc.MATERIAL_DTYPE))
     cfg = rt.config_rtiow(830, 750, 50).record().view(orc.CONFIG_DTYPE)
     # calibrate with two samples per pixel, then size the sample to the time target
@@ -61,7 +73,10 @@ def cpu_baseline(spheres, materials, seconds_target=15.0):
         "value": rays / dt / 1e6,
         "unit": "Mrays/s",
         "cores": threads,
+        "value_per_core": rays / dt / 1e6 / threads,
+        "machine_cores": os.cpu_count(),
         "kind": "port",
+        "build": "g++ -O3 -ffp-contract=off, one thread per core, pixels handed out dynamically",
         "sample": "830x466, %d of 750 spp, depth 50, %d rays in %.1f s; C++ f64 restatement of the Rayon loop, not Rayon" % (spp, rays, dt),
         "mean_path_length": rays / (830.0 * 466 * spp),
         "node_visits_per_ray": visits / rays,
@@ -70,12 +85,17 @@ def cpu_baseline(spheres, materials, seconds_target=15.0):
 
 
 def measured_traffic():
-    """HBM bytes per launch of the default workload from the committed counter profile, or None."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    try:
-        return json.load(open(path))
-    except (OSError, ValueError):
-        return None
+    """HBM bytes per launch of the default workload from the newest committed counter profile (a separate rocprofv3
+    --pmc run of this same command; counters cannot be collected from inside the timed run), or None."""
+    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            out = json.load(open(path))
+            out["file"] = "profiles/" + name
+            return out
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def main():
@@ -95,7 +115,7 @@ def main():
     import torch.distributed as dist
 
     import raytracer_amd as rt
-    from raytracer_amd.parallel import render_sample_split, render_tile_split
+    from raytracer_amd.parallel import render_sample_split
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -107,6 +127,9 @@ def main():
     torch.cuda.set_device(local_rank)
     distributed = world_size > 1 or args.force_distributed
     if distributed:
+        if world_size == 1:  # --force-distributed without a launcher: a process group of one
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517")):
+                os.environ.setdefault(k, v)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     rt.set_device(local_rank)  # the library's HIP runtime is not torch's: select the rank's GPU there too
@@ -135,7 +158,12 @@ def main():
             if args.force_distributed and world_size == 1:
                 dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)  # the collective of the N > 1 path, on one rank
         else:
-            render_tile_split(render, w, h, 0, total_spp, rank, world_size)
+            # one launch per rank: the rank's tile rows of the whole frame (dealt round-robin), as rt_render_multi does
+            shard = cam.partition(world_size, rt.PARTITION_TILES, spp_begin=0, spp_end=total_spp)[rank]
+            st = cam.render_shard_device(world, frame.data_ptr(), shard, seed=12345, stream=stream)
+            last["rays"] += st["rays"]
+            last["ms"] += st["kernel_ms"]
+            last["launches"] += 1
 
     def fence():
         if distributed:
@@ -190,9 +218,19 @@ def main():
             cb = cpu_baseline(spheres, materials)
             out["cpu_baseline"] = cb
             v_bar, p_bar, source = cb["node_visits_per_ray"], cb["sphere_tests_per_ray"], "cpu oracle sample of this run"
+        if "cpu_baseline" in out:
+            cb = out["cpu_baseline"]
+            out["speedup_vs_cpu"] = {
+                "vs_all_cores": out["value"] / cb["value"],
+                "vs_one_core": out["value"] / cb["value_per_core"],
+                "target_1000x_met": {"vs_all_cores": out["value"] / cb["value"] >= 1000.0, "vs_one_core": out["value"] / cb["value_per_core"] >= 1000.0},
+            }
         k_ms = kernel_ms / max(1, launches)
         rays_per_launch = rays / max(1, launches)
         flops = rays_per_launch * flops_per_ray(v_bar, p_bar)
+        # the node tests run in f32, the sphere tests and shading in f64: the time the work would take at both peaks
+        f32_flops, f64_flops = rays_per_launch * 25.0 * v_bar, rays_per_launch * (28.0 * p_bar + 60.0)
+        ideal_s = f32_flops / (FP32_VECTOR_PEAK_TFLOPS * 1e12) + f64_flops / (FP64_VECTOR_PEAK_TFLOPS * 1e12)
         traffic = measured_traffic() if (world_size == 1 and args.width == 3840 and args.spp == 1000 and args.depth == 50) else None
         out["roofline"] = {
             "bound": "valu",
@@ -201,15 +239,24 @@ def main():
             "peak": FP32_VECTOR_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": flops / (k_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+            "frac_meaning": "the reference's algorithmic flops per second over the FP32 vector peak",
             "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+            "traffic_replayed_from": traffic["file"] if traffic else None,
             "kernel_ms": k_ms,
             "flops_per_ray": flops_per_ray(v_bar, p_bar),
             "per_ray_counts_from": source,
-            "hbm_GBs_measured": traffic["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 if traffic else None,
+            "by_precision": {
+                "f32_flops_per_ray": 25.0 * v_bar,
+                "f64_flops_per_ray": 28.0 * p_bar + 60.0,
+                "f32_peak": FP32_VECTOR_PEAK_TFLOPS,
+                "f64_peak": FP64_VECTOR_PEAK_TFLOPS,
+                "frac_of_mixed_ceiling": ideal_s / (k_ms * 1e-3),
+            },
+            "hbm_GBs_replayed": traffic["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 if traffic else None,
             "hbm_peak_GBs": HBM_PEAK_GBS,
             "note": "the whole scene (nodes, spheres, materials: 93 KB) lives in LDS, so neither HBM nor MFMA binds; "
-                    "the kernel is bound by vector-ALU issue: the vector units issue all the time (see issue), "
-                    "with about 60 % of the lanes active per instruction",
+                    "the kernel is bound by vector-ALU issue.  traffic and issue are not measured in this run: they are "
+                    "replayed from the committed rocprofv3 --pmc profile of this same command (traffic_replayed_from)",
         }
         if traffic and "issue" in traffic:  # counter profile of the same workload: how busy the vector units are
             issue = traffic["issue"]
@@ -218,7 +265,7 @@ def main():
                 "simd_cycles_per_valu_instruction": issue["simd_cycles_per_valu_instruction"],
                 "mean_active_lanes_per_valu_instruction": issue["mean_active_lanes_per_valu_instruction"],
                 "measured_cycles_per_instruction_alone": "4.0-4.5 (fma, min/max, compare, select, f64), 2.5 (32-bit add, mul, xor, mov)",
-                "source": "profiles/r01_hbm_traffic.json, profiles/r01_valu_rate.txt",
+                "replayed_from": traffic["file"] + ", profiles/r01_valu_rate.txt",
             }
         print(json.dumps(out))
     if distributed:

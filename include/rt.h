@@ -88,8 +88,19 @@ typedef struct rt_rect {
   uint32_t x0, y0, x1, y1;
 } rt_rect;
 
+/* A share of a render request: the tile rows (8 pixel rows each, counted from rect.y0) of `rect` whose index is
+ * row_first modulo row_stride, for samples [spp_begin, spp_end).  row_first 0 and row_stride 1 name the whole
+ * rectangle.  Every share of a rectangle is summed exactly as the whole would be, so frames put together from
+ * tile-row shares are bit for bit the unshared frame. */
+typedef struct rt_shard {
+  rt_rect rect;
+  uint32_t row_first, row_stride;
+  uint32_t spp_begin, spp_end;
+} rt_shard;
+
 /* What one render call did.  kernel_ms is measured with HIP events on the
- * stream the kernels ran on. */
+ * stream the kernels ran on.  node_steps and sphere_tests are only counted by the instrumented
+ * kernel (RT_PROFILE_BLOCKS set in the environment) and are 0 otherwise. */
 typedef struct rt_render_stats {
   uint64_t rays;        /* closest-hit queries (primary + secondary), one per BVH::hit call of the reference */
   uint64_t samples;     /* camera paths started */
@@ -111,7 +122,7 @@ typedef struct rt_scene_info {
   double build_ms;          /* BVH build (+ flatten on the host path) */
   uint64_t lds_bytes;       /* LDS each workgroup of the tree-walking kernels uses for this scene */
   uint32_t builder;         /* RT_BUILD_* that made the tree (the device builder falls back to the host for very deep trees) */
-  uint32_t reserved;
+  uint32_t n_devices;       /* copies of the scene (1 unless made by rt_scene_create_multi); `device` is the first one's */
 } rt_scene_info;
 
 typedef struct rt_scene rt_scene;
@@ -147,6 +158,12 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_materia
 enum { RT_BUILD_HOST_SAH = 0, RT_BUILD_DEVICE_LBVH = 1 };
 int rt_scene_create_ex(const rt_sphere* spheres, size_t n_spheres, const rt_material* materials, size_t n_materials, uint32_t builder,
                        rt_scene** out);
+/* `BVH::new` for a host that owns several GPUs (src/main.rs:84 builds one tree; here every device gets a copy
+ * of it, the host tree being built once).  devices: n_devices HIP ordinals, or NULL for every visible device
+ * (at most 16; an ordinal may repeat).  The single-device entry points use the first copy; rt_render_multi and
+ * rt_render_ppm use all of them. */
+int rt_scene_create_multi(const rt_sphere* spheres, size_t n_spheres, const rt_material* materials, size_t n_materials, uint32_t builder,
+                          const int32_t* devices, size_t n_devices, rt_scene** out);
 int rt_scene_destroy(rt_scene* scene);
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
 
@@ -213,6 +230,31 @@ int rt_render(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32
 int rt_render_device(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
                      const rt_rect* tile, double* rgb_sum_dev, void* stream, rt_render_stats* stats);
 
+/* rt_render_device for one share of a request (see rt_shard): what each GPU of a node, or each process of a
+ * multi-process job, calls with its own share.  shard->rect must lie inside the image. */
+int rt_render_shard_device(const rt_scene* scene, const rt_config* cfg, uint64_t seed, const rt_shard* shard, double* rgb_sum_dev,
+                           void* stream, rt_render_stats* stats);
+
+/* How a frame is shared out over the GPUs of a node (every (pixel, sample) of src/camera.rs:144-151 is independent):
+ * RT_PARTITION_TILES   tile rows dealt round-robin, all samples; nothing is exchanged, the result is bit for bit
+ *                      the single-GPU frame;
+ * RT_PARTITION_SAMPLES contiguous sample ranges of the whole rectangle; the per-device frames are added in device
+ *                      order (equal to the single-GPU frame up to the rounding of those additions). */
+enum { RT_PARTITION_TILES = 0, RT_PARTITION_SAMPLES = 1 };
+
+/* The shares rt_render_multi gives to n_devices devices (host only; shards must hold n_devices entries). */
+int rt_partition(const rt_config* cfg, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile, uint32_t partition, uint32_t n_devices,
+                 rt_shard* shards);
+
+/* rt_render on every device of a scene made by rt_scene_create_multi (one host thread per device): the
+ * parallel part of `Camera::render` (src/camera.rs:140-155) spread over the node.  Adds into rgb_sum (host memory)
+ * like rt_render.  stats: rays and samples summed over the devices, kernel_ms the slowest device's.  With the
+ * sample partition the frames are brought together over the devices' peer links (each device sums one slice
+ * of all frames), or through copies to the first device where peers cannot read each other.  One such call per
+ * scene runs at a time. */
+int rt_render_multi(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile,
+                    uint32_t partition, double* rgb_sum, rt_render_stats* stats);
+
 /* Tuning knobs and test hooks; not part of the stable interface.  Known names:
  * "inner_min" (lanes of 64 that must want the inner-node block for a wave to run
  * it without counting the other blocks), "leaf_min" (lanes waiting at leaves that make the leaf block run between
@@ -221,7 +263,10 @@ int rt_render_device(const rt_scene* scene, const rt_config* cfg, uint64_t seed,
  * call's sample range is cut into units of work) -- none of these changes which
  * samples are rendered; "force_global_stack" (scenes created while it is 1 keep
  * their traversal stacks in global memory, the path trees deeper than 35 levels
- * take).  With RT_PROFILE_BLOCKS set in the environment, rt_render* runs the
+ * take); "force_staged_sum" (rt_render_multi adds sample-split frames through copies to the first
+ * device even where peers can read each other).  inner_min and leaf_min must be whole numbers in 1 .. 64,
+ * both_min in 0 .. 64; other values are refused.  The knobs are process-wide atomics: a render call reads them
+ * once when it starts.  With RT_PROFILE_BLOCKS set in the environment, rt_render* runs the
  * instrumented variant of the render kernel and prints, per code block, runs,
  * mean active lanes and cycles to stderr (slower; results unchanged). */
 int rt_debug_set(const char* name, double value);
@@ -245,7 +290,9 @@ int rt_write_ppm_bytes(int fd, const uint8_t* rgb, uint32_t width, uint32_t heig
 /* All of `Camera::render` (src/camera.rs:138-165) in one call: renders
  * cfg->samples_per_pixel samples of every pixel into a frame kept on the device,
  * quantises it there, copies 3 bytes per pixel back and writes the PPM text to
- * fd.  The text is what rt_render + rt_write_ppm produce. */
+ * fd.  The text is what rt_render + rt_write_ppm produce.  A scene made by
+ * rt_scene_create_multi is rendered by all its devices (tile rows dealt round-robin);
+ * the text is the same for any number of devices. */
 int rt_render_ppm(const rt_scene* scene, const rt_config* cfg, uint64_t seed, int fd, rt_render_stats* stats);
 
 /* Seeded restatement of the scene of src/main.rs:42-82 (4 fixed spheres and a

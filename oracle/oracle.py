@@ -343,3 +343,107 @@ def write_ppm(path, rgb_sum, w, h, spp):
     rc = lib().orc_write_ppm(path.encode(), _p(rgb), C.c_uint32(w), C.c_uint32(h), C.c_uint64(spp))
     if rc:
         raise OSError("cannot write " + path)
+
+
+# ---- Scenes: the oracle's own restatement of src/main.rs:42-82 and of the stress fields ----
+# Written in numpy on purpose: it shares no code with the library's generator (csrc/rt_host.cpp), so that the
+# fixtures and parity tests do not take the scene from the code under test.
+DOM_SCENE = 3
+
+
+def philox_pairs(seed, pixel, sample, slot, domain):
+    """Philox4x32-10 (Salmon et al. 2011) over arrays: key = seed, counter = (pixel, sample, slot, domain).
+    Returns two arrays of uniforms in [0, 1): (u64 >> 11) * 2^-53 of output words (0, 1) and (2, 3)."""
+    pixel = np.asarray(pixel, dtype=np.uint64)
+    c = [pixel & np.uint64(0xFFFFFFFF), np.full_like(pixel, sample), np.full_like(pixel, slot), np.full_like(pixel, domain)]
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32, p0 & m32]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    scale = 1.0 / 9007199254740992.0
+    u0 = (((c[1] << np.uint64(32)) | c[0]) >> np.uint64(11)).astype(np.float64) * scale
+    u1 = (((c[3] << np.uint64(32)) | c[2]) >> np.uint64(11)).astype(np.float64) * scale
+    return u0, u1
+
+
+def _object_draws(seed, ids, n_draws):
+    """Uniform number k of object `id` is half k % 2 of the Philox block (id, 0, k // 2, DOM_SCENE)."""
+    d = []
+    for slot in range((n_draws + 1) // 2):
+        u0, u1 = philox_pairs(seed, ids, 0, slot, DOM_SCENE)
+        d += [u0, u1]
+    return d
+
+
+def _random_materials(seed, ids, materials, p_lambertian, p_metal, max_fuzz):
+    """The three material kinds of src/main.rs:64-79 for objects `ids`: draw 2 picks the kind
+    (`gen_range(0..3)` is p = 1/3 each); Lambertian albedo = random::<DVec3>() * random::<DVec3>() (draws 4..6 times
+    draws 7..9, src/main.rs:67); Metal albedo in [0.5, 1]^3 and fuzz in [0, max_fuzz) (src/main.rs:72-73);
+    otherwise Dielectric with ir 1.5 (src/main.rs:77)."""
+    d = _object_draws(seed, ids, 10)
+    lam = d[2] < p_lambertian
+    met = ~lam & (d[2] < p_lambertian + p_metal)
+    die = ~lam & ~met
+    typ = np.where(lam, 0, np.where(met, 1, 2)).astype(np.uint32)
+    albedo = np.zeros((len(ids), 3))
+    for k in range(3):
+        albedo[:, k] = np.where(lam, d[4 + k] * d[7 + k], np.where(met, 0.5 + 0.5 * d[4 + k], 0.0))
+    materials["type"][ids] = typ
+    materials["albedo"][ids] = albedo
+    materials["param"][ids] = np.where(met, max_fuzz * d[7], np.where(die, 1.5, 0.0))
+    return d
+
+
+def scene_rtiow(seed=1):
+    """src/main.rs:42-82: ground, three big spheres, then the 22 x 22 grid of small ones, every one pushed
+    (src/main.rs:80); object n uses material n."""
+    spheres = np.zeros(488, dtype=SPHERE_DTYPE)
+    materials = np.zeros(488, dtype=MATERIAL_DTYPE)
+    spheres["mat"] = np.arange(488)
+    fixed = [((0.0, -1000.0, 0.0), 1000.0, 0, (0.5, 0.5, 0.5), 0.0),   # src/main.rs:45-47
+             ((0.0, 1.0, 0.0), 1.0, 2, (0.0, 0.0, 0.0), 1.5),           # src/main.rs:49
+             ((-4.0, 1.0, 0.0), 1.0, 0, (0.4, 0.2, 0.1), 0.0),          # src/main.rs:51-52
+             ((4.0, 1.0, 0.0), 1.0, 1, (0.7, 0.6, 0.5), 0.0)]           # src/main.rs:54-55
+    for k, (c, r, t, alb, param) in enumerate(fixed):
+        spheres[k]["c"], spheres[k]["r"] = c, r
+        materials[k]["type"], materials[k]["albedo"], materials[k]["param"] = t, alb, param
+    ids = np.arange(4, 488)
+    grid = ids - 4
+    a, b = grid // 22 - 11, grid % 22 - 11                              # for a in -11..11 { for b in -11..11
+    d = _random_materials(seed, ids, materials, 1.0 / 3.0, 1.0 / 3.0, 1.0)
+    spheres["c"][ids, 0] = a + 0.9 * d[0]                               # src/main.rs:61
+    spheres["c"][ids, 1] = 0.2
+    spheres["c"][ids, 2] = b + 0.9 * d[1]
+    spheres["r"][ids] = 0.2
+    return spheres, materials
+
+
+def scene_field(seed, n_small, p_lambertian, p_metal, max_fuzz=1.0):
+    """The stress fields: the ground sphere of src/main.rs:46 and n_small spheres of radius 0.2 resting on it, on a
+    square grid of spacing 1 with the reference's jitter of 0.9 (src/main.rs:61), materials drawn as in
+    src/main.rs:64-79 with the given probabilities."""
+    R = 1000.0
+    n = n_small + 1
+    spheres = np.zeros(n, dtype=SPHERE_DTYPE)
+    materials = np.zeros(n, dtype=MATERIAL_DTYPE)
+    spheres["mat"] = np.arange(n)
+    spheres[0]["c"], spheres[0]["r"] = (0.0, -R, 0.0), R
+    materials[0]["albedo"] = (0.5, 0.5, 0.5)
+    if n_small == 0:
+        return spheres, materials
+    side = int(np.ceil(np.sqrt(float(n_small))))
+    half = float(side // 2)
+    ids = np.arange(1, n)
+    k = ids - 1
+    d = _random_materials(seed, ids, materials, p_lambertian, p_metal, max_fuzz)
+    x = (k % side).astype(np.float64) - half + 0.9 * d[0]
+    z = (k // side).astype(np.float64) - half + 0.9 * d[1]
+    spheres["c"][ids, 0] = x
+    spheres["c"][ids, 1] = np.sqrt(np.maximum(R * R - x * x - z * z, 0.0)) - R + 0.2
+    spheres["c"][ids, 2] = z
+    spheres["r"][ids] = 0.2
+    return spheres, materials

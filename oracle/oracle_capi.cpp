@@ -79,7 +79,7 @@ void orc_sphere_hit_batch(const double* c, double radius, const double* org, con
   Sphere s{ld(c), radius, 0};
   for (size_t i = 0; i < n; ++i) {
     Ray r = ray_new(ld(org + 3 * i), ld(dir + 3 * i));
-    HitRecord hr;
+    HitRecord hr{};
     bool h = sphere_hit(s, 0, r, Interval{tmin, tmax}, hr);
     hit[i] = h;
     if (h) {
@@ -129,7 +129,7 @@ void orc_trace_batch(void* h, const double* org, const double* dir, size_t n, do
   TraceStats ts;
   for (size_t i = 0; i < n; ++i) {
     Ray r = ray_new(ld(org + 3 * i), ld(dir + 3 * i));
-    HitRecord hr;
+    HitRecord hr{};
     if (bvh_hit(sc.bvh, r, Interval{tmin, tmax}, hr, &ts)) {
       prim[i] = hr.prim;
       t[i] = hr.t;

@@ -375,7 +375,7 @@ static inline bool bvh_hit(const BVH& bvh, const Ray& r, Interval ray_t, HitReco
     } else {
       for (size_t pi : node.indices) {
         if (st) st->sphere_tests++;
-        HitRecord hr;
+        HitRecord hr{};
         if (sphere_hit(bvh.primitives[pi], (int32_t)pi, r, ray_t, hr)) {
           ray_t.max = hr.t;
           best = hr;
@@ -652,7 +652,7 @@ static inline ScatterDraw draw_for_bounce(PathRng& g, const Material& m, const H
 // is formed in the reference's order.
 static inline V3 ray_colour(const Scene& sc, const Ray& r, uint64_t depth, uint32_t bounce, PathRng& g, TraceStats* st) {
   if (depth == 0) return v3(0, 0, 0);
-  HitRecord hr;
+  HitRecord hr{};
   if (!bvh_hit(sc.bvh, r, Interval{1e-3, INF}, hr, st)) {
     V3 unit_direction = normalize(r.direction);
     double a = (unit_direction.y + 1.0) / 2.0;

@@ -56,9 +56,12 @@ SCENE_INFO_DTYPE = np.dtype(
         ("build_ms", "<f8"),
         ("lds_bytes", "<u8"),
         ("builder", "<u4"),
-        ("reserved", "<u4"),
+        ("n_devices", "<u4"),
     ]
 )
+SHARD_DTYPE = np.dtype([("x0", "<u4"), ("y0", "<u4"), ("x1", "<u4"), ("y1", "<u4"), ("row_first", "<u4"), ("row_stride", "<u4"),
+                        ("spp_begin", "<u4"), ("spp_end", "<u4")])
+PARTITION_TILES, PARTITION_SAMPLES = 0, 1
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
 BUILD_HOST_SAH, BUILD_DEVICE_LBVH = 0, 1
@@ -73,6 +76,7 @@ EXPORTS = [
     "rt_camera_derive",
     "rt_scene_create",
     "rt_scene_create_ex",
+    "rt_scene_create_multi",
     "rt_scene_destroy",
     "rt_scene_get_info",
     "rt_bvh_build",
@@ -86,6 +90,9 @@ EXPORTS = [
     "rt_primary_rays",
     "rt_render",
     "rt_render_device",
+    "rt_render_shard_device",
+    "rt_partition",
+    "rt_render_multi",
     "rt_debug_set",
     "rt_quantise",
     "rt_write_ppm",

@@ -13,8 +13,8 @@ import sys
 import numpy as np
 
 from . import _lib
-from ._lib import (CAMERA_DTYPE, CONFIG_DTYPE, DIELECTRIC, LAMBERTIAN, MATERIAL_DTYPE, METAL, RECT_DTYPE, RENDER_STATS_DTYPE,
-                   SCENE_INFO_DTYPE, SPHERE_DTYPE, RtError, check, f3, ptr)
+from ._lib import (CAMERA_DTYPE, CONFIG_DTYPE, DIELECTRIC, LAMBERTIAN, MATERIAL_DTYPE, METAL, PARTITION_SAMPLES, PARTITION_TILES, RECT_DTYPE,
+                   RENDER_STATS_DTYPE, SCENE_INFO_DTYPE, SHARD_DTYPE, SPHERE_DTYPE, RtError, check, f3, ptr)
 
 _FIELDS = ["aspect_ratio", "image_width", "samples_per_pixel", "max_depth", "vfov", "lookfrom", "lookat", "vup", "defocus_angle",
            "focus_dist"]
@@ -167,9 +167,11 @@ class BVH:
     """`BVH::new(objects)` (src/bvh.rs:44-48) on the current HIP device.
 
     `objects` is a list of Sphere, or a pair (sphere records, material records).  builder: BUILD_HOST_SAH (the
-    reference's tree) or BUILD_DEVICE_LBVH (built on the GPU; same hits, a different tree)."""
+    reference's tree) or BUILD_DEVICE_LBVH (built on the GPU; same hits, a different tree).  devices: None for one
+    copy on the current device; "all" or a list of HIP ordinals for a copy on each (Camera.render and
+    Camera.render_multi then use all of them)."""
 
-    def __init__(self, objects, materials=None, builder=0):
+    def __init__(self, objects, materials=None, builder=0, devices=None):
         if materials is None and not isinstance(objects, np.ndarray):
             spheres, materials = flatten(list(objects))
         else:
@@ -177,8 +179,13 @@ class BVH:
             materials = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
         self.spheres, self.materials = spheres, materials
         h = C.c_void_p()
-        check(_lib.lib().rt_scene_create_ex(ptr(spheres), C.c_size_t(len(spheres)), ptr(materials), C.c_size_t(len(materials)),
-                                            C.c_uint32(builder), C.byref(h)))
+        if devices is None:
+            check(_lib.lib().rt_scene_create_ex(ptr(spheres), C.c_size_t(len(spheres)), ptr(materials), C.c_size_t(len(materials)),
+                                                C.c_uint32(builder), C.byref(h)))
+        else:
+            devs = None if isinstance(devices, str) else np.ascontiguousarray(devices, dtype=np.int32)
+            check(_lib.lib().rt_scene_create_multi(ptr(spheres), C.c_size_t(len(spheres)), ptr(materials), C.c_size_t(len(materials)),
+                                                   C.c_uint32(builder), ptr(devs), C.c_size_t(0 if devs is None else len(devs)), C.byref(h)))
         self._h = h
 
     new = classmethod(lambda cls, objects: cls(objects))
@@ -291,6 +298,43 @@ class Camera:
         check(_lib.lib().rt_render_device(bvh._h, ptr(self.config.record()), C.c_uint64(seed), C.c_uint32(spp_begin), C.c_uint32(spp_end),
                                           ptr(rect), C.c_void_p(rgb_sum_ptr), C.c_void_p(stream or 0), ptr(stats)))
         return {k: stats[k][0].item() for k in RENDER_STATS_DTYPE.names}
+
+    def render_shard_device(self, bvh, rgb_sum_ptr, shard, seed=0, stream=None):
+        """One share of a frame (a SHARD_DTYPE record, e.g. from `partition`) added into a device buffer."""
+        stats = np.zeros(1, dtype=RENDER_STATS_DTYPE)
+        shard = np.ascontiguousarray(shard, dtype=SHARD_DTYPE).reshape(1)
+        check(_lib.lib().rt_render_shard_device(bvh._h, ptr(self.config.record()), C.c_uint64(seed), ptr(shard), C.c_void_p(rgb_sum_ptr),
+                                                C.c_void_p(stream or 0), ptr(stats)))
+        return {k: stats[k][0].item() for k in RENDER_STATS_DTYPE.names}
+
+    def partition(self, n_devices, partition=PARTITION_TILES, spp_begin=0, spp_end=None, tile=None):
+        """The shares `render_multi` gives to n_devices devices: an array of SHARD_DTYPE records."""
+        if spp_end is None:
+            spp_end = self.config.get("samples_per_pixel")
+        rect = None
+        if tile is not None:
+            rect = np.zeros(1, dtype=RECT_DTYPE)
+            rect["x0"], rect["y0"], rect["x1"], rect["y1"] = tile
+        shards = np.zeros(n_devices, dtype=SHARD_DTYPE)
+        check(_lib.lib().rt_partition(ptr(self.config.record()), C.c_uint32(spp_begin), C.c_uint32(spp_end), ptr(rect), C.c_uint32(partition),
+                                      C.c_uint32(n_devices), ptr(shards)))
+        return shards
+
+    def render_multi(self, bvh, seed=0, spp_begin=0, spp_end=None, tile=None, partition=PARTITION_TILES, rgb_sum=None):
+        """render_sum on every device of a scene created with devices=...: per-pixel sums on the host."""
+        w, h = self.config.get("image_width"), self.image_height
+        if spp_end is None:
+            spp_end = self.config.get("samples_per_pixel")
+        if rgb_sum is None:
+            rgb_sum = np.zeros((h, w, 3))
+        rect = None
+        if tile is not None:
+            rect = np.zeros(1, dtype=RECT_DTYPE)
+            rect["x0"], rect["y0"], rect["x1"], rect["y1"] = tile
+        stats = np.zeros(1, dtype=RENDER_STATS_DTYPE)
+        check(_lib.lib().rt_render_multi(bvh._h, ptr(self.config.record()), C.c_uint64(seed), C.c_uint32(spp_begin), C.c_uint32(spp_end),
+                                         ptr(rect), C.c_uint32(partition), ptr(rgb_sum), ptr(stats)))
+        return rgb_sum, {k: stats[k][0].item() for k in RENDER_STATS_DTYPE.names}
 
     def render(self, bvh, seed=0, fd=1):
         """`Camera::render(&self, &BVH)`: PPM text to fd (stdout), elapsed time to stderr.  The frame stays on the

@@ -5,6 +5,8 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <exception>
+#include <system_error>
 #include <thread>
 
 namespace rta {
@@ -55,7 +57,8 @@ inline unsigned host_threads() {
   return std::max(1u, std::min(hw ? hw : 1u, 16u));
 }
 
-// Runs f(part, begin, end) over [lo, hi) cut into `parts` contiguous pieces, one thread each.
+// Runs f(part, begin, end) over [lo, hi) cut into `parts` contiguous pieces, one thread each; a piece whose
+// thread cannot be created runs on the calling thread.  f must not throw.
 template <class F>
 void for_parts(size_t lo, size_t hi, unsigned parts, F f) {
   if (parts <= 1) {
@@ -63,9 +66,18 @@ void for_parts(size_t lo, size_t hi, unsigned parts, F f) {
     return;
   }
   std::vector<std::thread> th;
+  th.reserve(parts - 1);
   const size_t n = hi - lo;
-  for (unsigned p = 1; p < parts; ++p) th.emplace_back(f, p, lo + n * p / parts, lo + n * (p + 1) / parts);
+  unsigned started = 1;  // pieces [1, started) have a thread
+  for (; started < parts; ++started) {
+    try {
+      th.emplace_back(f, started, lo + n * started / parts, lo + n * (started + 1) / parts);
+    } catch (const std::system_error&) {
+      break;
+    }
+  }
   f(0u, lo, lo + n / parts);
+  for (unsigned p = started; p < parts; ++p) f(p, lo + n * p / parts, lo + n * (p + 1) / parts);
   for (auto& t : th) t.join();
 }
 
@@ -222,9 +234,32 @@ struct Builder {
       if (nl >= grain && nr >= grain / 4) {
         Subtree::Hole hole{out.nodes.size(), std::make_unique<Subtree>(), std::make_unique<Subtree>()};
         Subtree &left = *hole.left, &right = *hole.right;
-        std::thread worker([&]() { build(lo, lo + nl, depth + 1, left); });
-        build(lo + nl, hi, depth + 1, right);
-        worker.join();
+        // The left subtree on a thread of its own where one can be had.  An exception in either half (out of
+        // memory) is carried to this thread and rethrown once both halves have stopped.
+        std::exception_ptr left_error, right_error;
+        auto build_left = [&]() {
+          try {
+            build(lo, lo + nl, depth + 1, left);
+          } catch (...) {
+            left_error = std::current_exception();
+          }
+        };
+        std::thread worker;
+        try {
+          worker = std::thread(build_left);
+        } catch (const std::system_error&) {
+        }
+        try {
+          build(lo + nl, hi, depth + 1, right);
+        } catch (...) {
+          right_error = std::current_exception();
+        }
+        if (worker.joinable())
+          worker.join();
+        else if (!right_error)
+          build_left();
+        if (left_error) std::rethrow_exception(left_error);
+        if (right_error) std::rethrow_exception(right_error);
         out.nodes[me].skip = left.total + 1;  // src/bvh.rs:126-130
         out.total += left.total + right.total;
         out.depth = std::max({out.depth, left.depth, right.depth});

@@ -3,13 +3,18 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh_builder.h"
@@ -27,6 +32,32 @@ thread_local std::string g_error;
 int fail(int code, const std::string& msg) {
   g_error = msg;
   return code;
+}
+
+// Runs the body of an entry point; no C++ exception leaves the library.
+template <class F>
+int guarded(const char* who, F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    try {
+      g_error = std::string(who) + ": out of host memory";
+    } catch (...) {
+    }
+    return RT_ERR_LIMIT;
+  } catch (const std::exception& e) {
+    try {
+      g_error = std::string(who) + ": " + e.what();
+    } catch (...) {
+    }
+    return RT_ERR_INVALID;
+  } catch (...) {
+    try {
+      g_error = std::string(who) + ": unknown failure";
+    } catch (...) {
+    }
+    return RT_ERR_INVALID;
+  }
 }
 
 #define RT_HIP(call)                                                                                         \
@@ -48,7 +79,7 @@ struct DevBuf {
   }
 };
 
-struct DeviceGuard {  // makes the scene's device current for the duration of a call
+struct DeviceGuard {  // makes a device current for the duration of a call
   int prev = -1;
   hipError_t status;
   explicit DeviceGuard(int dev) {
@@ -60,38 +91,106 @@ struct DeviceGuard {  // makes the scene's device current for the duration of a 
   }
 };
 
+// Tunables (rt_debug_set).  Atomics: a render call reads each of them once, when it starts.
 // Lanes (of 64) that must want the inner-node block for a wave to run it without looking at the other blocks.
-uint32_t g_inner_min = 10;
+std::atomic<uint32_t> g_inner_min{10};
 // Lanes that must want the other traversal block (inner or leaf) for it to run in the same round as the one that is due.
-uint32_t g_both_min = 8;
+std::atomic<uint32_t> g_both_min{8};
 // Lanes waiting at leaves that make the leaf block run between inner-node rounds.
-uint32_t g_leaf_min = 10;
+std::atomic<uint32_t> g_leaf_min{10};
 // Samples of one pixel that make a unit of work (the sample range is cut into chunks of about this size).
-uint32_t g_chunk_spp = 64;
+std::atomic<uint32_t> g_chunk_spp{64};
 // Fewest units of work a call is cut into (32 per lane of the chip).
-uint64_t g_target_units = 1u << 25;
-uint64_t g_batches_per_wave = 32;
+std::atomic<uint64_t> g_target_units{1u << 25};
+std::atomic<uint64_t> g_batches_per_wave{32};
 // Test hook: scenes created while this is set keep their traversal stacks in global memory, as very deep trees must.
-bool g_force_global_stack = false;
+std::atomic<bool> g_force_global_stack{false};
+// Test hook: rt_render_multi brings the frames of a sample split together through a copy on the first device even
+// where the devices can read each other's memory.
+std::atomic<bool> g_force_staged_sum{false};
+
+// Partial sums of an allocating render call never exceed this; the sample range is cut into fewer chunks instead.
+constexpr uint64_t kWorkspaceLimit = 4ull << 30;
+
+// Device memory a render call needs beyond its inputs and outputs.
+struct Workspace {
+  unsigned long long* counters = nullptr;  // kRenderCounters words
+  double* partial = nullptr;               // per-chunk sums
+  size_t partial_cap = 0;
+  uint32_t* gstack = nullptr;  // traversal stacks of trees too deep for LDS
+  size_t gstack_cap = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool fixed = false;  // carved out of the library's static device array: cannot grow, owns nothing
+  ~Workspace() {
+    if (fixed) return;
+    if (counters) (void)hipFree(counters);
+    if (partial) (void)hipFree(partial);
+    if (gstack) (void)hipFree(gstack);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+  }
+};
+
+// One copy of a scene on one device.
+struct Replica {
+  int device = 0;
+  int num_cus = 0;
+  void *d_nodes = nullptr, *d_spheres = nullptr, *d_aux = nullptr, *d_materials = nullptr;
+  SceneDev dev{};
+  // Workspaces of finished calls, kept for the next ones (a call takes one for itself, so calls may overlap).
+  std::mutex pool_mu;
+  std::vector<std::unique_ptr<Workspace>> idle;
+  // rt_render_multi / rt_render_ppm: this device's frame, a second frame for sums staged through a copy, the
+  // quantised bytes, and pinned host memory for the way back.  Grow-only; guarded by rt_scene::multi_mu.
+  double* frame = nullptr;
+  size_t frame_cap = 0;
+  double* frame2 = nullptr;
+  size_t frame2_cap = 0;
+  uint8_t* bytes = nullptr;
+  size_t bytes_cap = 0;
+  void* pinned = nullptr;
+  size_t pinned_cap = 0;
+  hipStream_t stream = nullptr;
+
+  ~Replica() {
+    DeviceGuard g(device);
+    idle.clear();
+    for (void* p : {d_nodes, d_spheres, d_aux, d_materials, (void*)frame, (void*)frame2, (void*)bytes})
+      if (p) (void)hipFree(p);
+    if (pinned) (void)hipHostFree(pinned);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+hipError_t grow_device(void** p, size_t* cap, size_t bytes) {
+  if (bytes <= *cap) return hipSuccess;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) *cap = bytes;
+  return e;
+}
 
 }  // namespace
 
 struct rt_scene {
-  int device = 0;
-  int num_cus = 0;
+  std::vector<std::unique_ptr<Replica>> reps;  // reps[0] is the scene's home: the single-device entry points use it
+  std::vector<std::vector<uint8_t>> peer;      // peer[a][b]: device of replica a can read the memory of replica b's
   HostBvh host;
   size_t n_spheres = 0, n_materials = 0;
   std::vector<uint8_t> material_type;
-  void *d_nodes = nullptr, *d_spheres = nullptr, *d_aux = nullptr, *d_materials = nullptr;
-  SceneDev dev{};
   rt_scene_info info{};
+  std::mutex multi_mu;  // one multi-device call per scene at a time (they share the replicas' frames)
 };
 
 struct rt_host_bvh {
   HostBvh bvh;
 };
 
-static void dump_bvh(const HostBvh& b, double* boxes, int32_t* kind, uint64_t* skip_or_count, uint64_t* leaf_indices) {
+namespace {
+
+void dump_bvh(const HostBvh& b, double* boxes, int32_t* kind, uint64_t* skip_or_count, uint64_t* leaf_indices) {
   for (size_t i = 0; i < b.nodes.size(); ++i) {
     const HostNode& h = b.nodes[i];
     if (boxes) {
@@ -104,7 +203,7 @@ static void dump_bvh(const HostBvh& b, double* boxes, int32_t* kind, uint64_t* s
   if (leaf_indices) std::memcpy(leaf_indices, b.leaf_indices.data(), b.leaf_indices.size() * 8);
 }
 
-static int make_camera_dev(const rt_config* cfg, CameraDev* cam, const char* who) {
+int make_camera_dev(const rt_config* cfg, CameraDev* cam, const char* who) {
   if (!cfg) return fail(RT_ERR_INVALID, std::string(who) + ": cfg is null");
   std::string why = config_check(*cfg);
   if (!why.empty()) return fail(RT_ERR_INVALID, std::string(who) + ": " + why);
@@ -123,42 +222,106 @@ static int make_camera_dev(const rt_config* cfg, CameraDev* cam, const char* who
   return RT_OK;
 }
 
-extern "C" {
+// ------------------------------------------------------------ scene set-up ----
+// Uploads one copy of the scene to the current device (or builds the tree there) and plans its LDS image.
+int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, const std::vector<double>& mats,
+                 const std::vector<uint8_t>& material_type, bool on_device_wanted, const FlatBvh* flat_in, size_t max_depth, bool* on_device_out,
+                 uint32_t* depth_out, size_t* n_dev_nodes_out) {
+  RT_HIP(hipGetDevice(&rp.device));
+  hipDeviceProp_t prop;
+  RT_HIP(hipGetDeviceProperties(&prop, rp.device));
+  rp.num_cus = prop.multiProcessorCount;
 
-const char* rt_last_error(void) { return g_error.c_str(); }
+  DeviceTree tree;
+  bool on_device = false;
+  if (on_device_wanted) {
+    hipError_t e = device_build_lbvh(spheres, n, material_type.data(), nm, &tree, nullptr);
+    rp.d_nodes = tree.d_nodes;
+    rp.d_spheres = tree.d_spheres;
+    rp.d_aux = tree.d_aux;
+    RT_HIP(e);
+    if (tree.depth <= max_depth) {
+      on_device = true;
+    } else {  // a tree too deep for the traversal stack: the caller falls back to the host builder
+      (void)hipFree(rp.d_nodes);
+      (void)hipFree(rp.d_spheres);
+      (void)hipFree(rp.d_aux);
+      rp.d_nodes = rp.d_spheres = rp.d_aux = nullptr;
+      *on_device_out = false;
+      return RT_OK;
+    }
+  }
+  const FlatBvh& flat = *flat_in;
+  const size_t n_dev_nodes = on_device ? tree.n_nodes : flat.nodes.size();
+  const uint32_t tree_depth = on_device ? tree.depth : flat.depth;
 
-int rt_device_count(int* count) {
-  if (!count) return fail(RT_ERR_INVALID, "rt_device_count: null argument");
-  RT_HIP(hipGetDeviceCount(count));
+  // LDS plan for one workgroup per CU: the per-lane stacks are mandatory; then, while they
+  // fit, the top of the tree, the sphere records, the slots' shading data and the materials.
+  // A tree too deep for that keeps its stacks in global memory and LDS holds scene data only.
+  const uint32_t depth = tree_depth ? tree_depth : 1;
+  const size_t reserve = lds_fixed_bytes() + 64;
+  const bool stack_in_lds = depth <= max_depth && !g_force_global_stack.load();
+  const size_t stack_bytes = stack_in_lds ? (size_t)depth * kWorkgroup * 4 : 0;
+  size_t room = kLdsPerCu - stack_bytes - reserve;
+  const size_t node_bytes = n_dev_nodes * sizeof(DevNode), sph_bytes = n * sizeof(DevSphere);
+  const size_t aux_bytes = n * sizeof(DevSphereAux), mat_bytes = nm * 32;
+  uint32_t n_nodes_lds = (uint32_t)std::min(n_dev_nodes, room / lds_node_bytes());
+  room -= n_nodes_lds * lds_node_bytes();
+  uint32_t n_sph_lds = 0, n_aux_lds = 0, n_mat_lds = 0;
+  if (n_nodes_lds == n_dev_nodes) {
+    if (sph_bytes <= room) {
+      n_sph_lds = (uint32_t)n;
+      room -= sph_bytes;
+      if (aux_bytes <= room) {
+        n_aux_lds = (uint32_t)n;
+        room -= aux_bytes;
+        if (mat_bytes <= room) n_mat_lds = (uint32_t)nm;
+      }
+    }
+  }
+
+  if (!on_device) {
+    RT_HIP(hipMalloc(&rp.d_nodes, node_bytes ? node_bytes : 64));
+    RT_HIP(hipMalloc(&rp.d_spheres, sph_bytes ? sph_bytes : 32));
+    RT_HIP(hipMalloc(&rp.d_aux, aux_bytes ? aux_bytes : 16));
+    if (node_bytes) RT_HIP(hipMemcpy(rp.d_nodes, flat.nodes.data(), node_bytes, hipMemcpyHostToDevice));
+    if (sph_bytes) RT_HIP(hipMemcpy(rp.d_spheres, flat.spheres.data(), sph_bytes, hipMemcpyHostToDevice));
+    if (aux_bytes) RT_HIP(hipMemcpy(rp.d_aux, flat.aux.data(), aux_bytes, hipMemcpyHostToDevice));
+  }
+  RT_HIP(hipMalloc(&rp.d_materials, mat_bytes ? mat_bytes : 32));
+  if (mat_bytes) RT_HIP(hipMemcpy(rp.d_materials, mats.data(), mat_bytes, hipMemcpyHostToDevice));
+
+  SceneDev& dev = rp.dev;
+  dev.nodes = static_cast<const float4*>(rp.d_nodes);
+  dev.spheres = static_cast<const double2*>(rp.d_spheres);
+  dev.aux = static_cast<const double2*>(rp.d_aux);
+  dev.materials = static_cast<const double2*>(rp.d_materials);
+  dev.n_nodes = (uint32_t)n_dev_nodes;
+  dev.n_spheres = (uint32_t)n;
+  dev.n_materials = (uint32_t)nm;
+  dev.n_nodes_lds = n_nodes_lds;
+  dev.n_spheres_lds = n_sph_lds;
+  dev.n_aux_lds = n_aux_lds;
+  dev.n_materials_lds = n_mat_lds;
+  dev.stack_cap = depth;
+  dev.stack_in_lds = stack_in_lds ? 1u : 0u;
+  dev.root = on_device ? tree.root : flat.root;
+  dev.bound = on_device ? tree.bound : flat.bound;
+  bool single = true;  // the device builder makes one-sphere leaves only
+  if (!on_device) {
+    auto one = [](uint32_t ref) { return !(ref & kRefLeaf) || ref == kRefNone || ((ref >> 24) & 0x7fu) == 1u; };
+    single = one(flat.root);
+    for (const DevNode& nd : flat.nodes) single = single && one(nd.ref0) && one(nd.ref1);
+  }
+  dev.single_leaves = single ? 1u : 0u;
+  *on_device_out = on_device;
+  *depth_out = tree_depth;
+  *n_dev_nodes_out = n_dev_nodes;
   return RT_OK;
 }
-int rt_device_set(int ordinal) {
-  RT_HIP(hipSetDevice(ordinal));
-  return RT_OK;
-}
-int rt_device_get(int* ordinal) {
-  if (!ordinal) return fail(RT_ERR_INVALID, "rt_device_get: null argument");
-  RT_HIP(hipGetDevice(ordinal));
-  return RT_OK;
-}
 
-void rt_config_default(rt_config* cfg) {
-  if (cfg) config_default(cfg);
-}
-
-int rt_camera_derive(const rt_config* cfg, rt_camera* out) {
-  if (!cfg || !out) return fail(RT_ERR_INVALID, "rt_camera_derive: null argument");
-  std::string why = config_check(*cfg);
-  if (!why.empty()) return fail(RT_ERR_INVALID, "rt_camera_derive: " + why);
-  camera_derive(*cfg, out);
-  return RT_OK;
-}
-
-int rt_scene_create(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, rt_scene** out) {
-  return rt_scene_create_ex(spheres, n, materials, nm, RT_BUILD_HOST_SAH, out);
-}
-
-int rt_scene_create_ex(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, uint32_t builder, rt_scene** out) {
+int create_scene(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, uint32_t builder, const int32_t* devices,
+                 size_t n_devices, bool current_device_only, rt_scene** out) {
   if (!out) return fail(RT_ERR_INVALID, "rt_scene_create: out is null");
   if (builder > RT_BUILD_DEVICE_LBVH) return fail(RT_ERR_INVALID, "rt_scene_create: unknown builder");
   *out = nullptr;
@@ -181,20 +344,30 @@ int rt_scene_create_ex(const rt_sphere* spheres, size_t n, const rt_material* ma
       return fail(RT_ERR_INVALID, "rt_scene_create: material " + std::to_string(i) + " has a non-finite field");
   }
 
-  rt_scene* sc = new (std::nothrow) rt_scene();
-  if (!sc) return fail(RT_ERR_LIMIT, "rt_scene_create: out of host memory");
-  struct Cleanup {
-    rt_scene* s;
-    ~Cleanup() {
-      if (s) rt_scene_destroy(s);
+  // The devices that get a copy: the current one, or the caller's list (an ordinal may repeat: two copies on one GPU).
+  std::vector<int> devs;
+  if (current_device_only) {
+    int cur = 0;
+    RT_HIP(hipGetDevice(&cur));
+    devs.push_back(cur);
+  } else {
+    int count = 0;
+    RT_HIP(hipGetDeviceCount(&count));
+    if (!devices) {
+      for (int d = 0; d < count; ++d) devs.push_back(d);
+    } else {
+      if (n_devices == 0) return fail(RT_ERR_INVALID, "rt_scene_create_multi: empty device list");
+      for (size_t k = 0; k < n_devices; ++k) {
+        if (devices[k] < 0 || devices[k] >= count)
+          return fail(RT_ERR_INVALID, "rt_scene_create_multi: device " + std::to_string(devices[k]) + " does not exist (" + std::to_string(count) + " visible)");
+        devs.push_back(devices[k]);
+      }
     }
-  } cleanup{sc};
+    if (devs.empty()) return fail(RT_ERR_HIP, "rt_scene_create_multi: no HIP device");
+    if (devs.size() > kMaxAddFrames) return fail(RT_ERR_LIMIT, "rt_scene_create_multi: at most 16 devices");
+  }
 
-  RT_HIP(hipGetDevice(&sc->device));
-  hipDeviceProp_t prop;
-  RT_HIP(hipGetDeviceProperties(&prop, sc->device));
-  sc->num_cus = prop.multiProcessorCount;
-
+  std::unique_ptr<rt_scene> sc(new rt_scene());
   sc->n_spheres = n;
   sc->n_materials = nm;
 
@@ -219,122 +392,468 @@ int rt_scene_create_ex(const rt_sphere* spheres, size_t n, const rt_material* ma
     }
   }
 
-  // The tree: built on the host with the reference's algorithm, or on the device (two or more
-  // spheres; a tree too deep for the traversal stack falls back to the host builder).
+  // The tree: built on the host with the reference's algorithm (once, then uploaded to every device), or on each
+  // device (two or more spheres; a tree too deep for the traversal stack falls back to the host builder).
   auto t0 = std::chrono::steady_clock::now();
   const size_t max_depth = (kLdsPerCu - lds_fixed_bytes() - 64 - 16 * 1024) / (kWorkgroup * 4);
+  bool want_device = builder == RT_BUILD_DEVICE_LBVH && n >= 2;
   FlatBvh flat;
-  DeviceTree tree;
+  bool have_flat = false;
   bool on_device = false;
-  if (builder == RT_BUILD_DEVICE_LBVH && n >= 2) {
-    hipError_t e = device_build_lbvh(spheres, n, sc->material_type.data(), nm, &tree, nullptr);
-    sc->d_nodes = tree.d_nodes;
-    sc->d_spheres = tree.d_spheres;
-    sc->d_aux = tree.d_aux;
-    RT_HIP(e);
-    if (tree.depth <= max_depth) {
-      on_device = true;
-    } else {
-      (void)hipFree(sc->d_nodes);
-      (void)hipFree(sc->d_spheres);
-      (void)hipFree(sc->d_aux);
-      sc->d_nodes = sc->d_spheres = sc->d_aux = nullptr;
-    }
-  }
-  if (!on_device) {
-    sc->host = build_bvh(spheres, n);
-    flat = flatten_bvh(sc->host, spheres, n);
-    for (auto& a : flat.aux) a.material |= (uint32_t)sc->material_type[a.material] << 30;
-  }
-  auto t1 = std::chrono::steady_clock::now();
-  const size_t n_dev_nodes = on_device ? tree.n_nodes : flat.nodes.size();
-  const uint32_t tree_depth = on_device ? tree.depth : flat.depth;
-
-  // LDS plan for one workgroup per CU: the per-lane stacks are mandatory; then, while they
-  // fit, the top of the tree, the sphere records, the slots' shading data and the materials.
-  // A tree too deep for that keeps its stacks in global memory (allocated per call) and LDS holds scene data only.
-  const uint32_t depth = tree_depth ? tree_depth : 1;
-  const size_t reserve = lds_fixed_bytes() + 64;
-  const bool stack_in_lds = depth <= max_depth && !g_force_global_stack;
-  const size_t stack_bytes = stack_in_lds ? (size_t)depth * kWorkgroup * 4 : 0;
-  size_t room = kLdsPerCu - stack_bytes - reserve;
-  const size_t node_bytes = n_dev_nodes * sizeof(DevNode), sph_bytes = n * sizeof(DevSphere);
-  const size_t aux_bytes = n * sizeof(DevSphereAux), mat_bytes = nm * 32;
-  uint32_t n_nodes_lds = (uint32_t)std::min(n_dev_nodes, room / lds_node_bytes());
-  room -= n_nodes_lds * lds_node_bytes();
-  uint32_t n_sph_lds = 0, n_aux_lds = 0, n_mat_lds = 0;
-  if (n_nodes_lds == n_dev_nodes) {
-    if (sph_bytes <= room) {
-      n_sph_lds = (uint32_t)n;
-      room -= sph_bytes;
-      if (aux_bytes <= room) {
-        n_aux_lds = (uint32_t)n;
-        room -= aux_bytes;
-        if (mat_bytes <= room) n_mat_lds = (uint32_t)nm;
+  uint32_t tree_depth = 0;
+  size_t n_dev_nodes = 0;
+  double build_ms = 0.0;
+  for (size_t k = 0; k < devs.size(); ++k) {
+    DeviceGuard g(devs[k]);
+    RT_HIP(g.status);
+    std::unique_ptr<Replica> rp(new Replica());
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (!want_device && !have_flat) {
+        sc->host = build_bvh(spheres, n);
+        flat = flatten_bvh(sc->host, spheres, n);
+        for (auto& a : flat.aux) a.material |= (uint32_t)sc->material_type[a.material] << 30;
+        have_flat = true;
       }
+      bool od = false;
+      int rc = make_replica(*rp, spheres, n, nm, mats, sc->material_type, want_device, &flat, max_depth, &od, &tree_depth, &n_dev_nodes);
+      if (rc) return rc;
+      if (want_device && !od) {  // too deep: every replica takes the host tree
+        want_device = false;
+        continue;
+      }
+      on_device = od;
+      break;
+    }
+    if (k == 0) build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    sc->reps.push_back(std::move(rp));
+  }
+
+  // Which replicas' devices can read each other's memory (xGMI / PCIe peer access), enabled once here.
+  const size_t R = sc->reps.size();
+  sc->peer.assign(R, std::vector<uint8_t>(R, 0));
+  for (size_t a = 0; a < R; ++a) {
+    DeviceGuard g(sc->reps[a]->device);
+    for (size_t b = 0; b < R; ++b) {
+      const int da = sc->reps[a]->device, db = sc->reps[b]->device;
+      if (da == db) {
+        sc->peer[a][b] = 1;
+        continue;
+      }
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) continue;
+      hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+      if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) sc->peer[a][b] = 1;
+      (void)hipGetLastError();
     }
   }
 
-  if (!on_device) {
-    RT_HIP(hipMalloc(&sc->d_nodes, node_bytes ? node_bytes : 64));
-    RT_HIP(hipMalloc(&sc->d_spheres, sph_bytes ? sph_bytes : 32));
-    RT_HIP(hipMalloc(&sc->d_aux, aux_bytes ? aux_bytes : 16));
-    if (node_bytes) RT_HIP(hipMemcpy(sc->d_nodes, flat.nodes.data(), node_bytes, hipMemcpyHostToDevice));
-    if (sph_bytes) RT_HIP(hipMemcpy(sc->d_spheres, flat.spheres.data(), sph_bytes, hipMemcpyHostToDevice));
-    if (aux_bytes) RT_HIP(hipMemcpy(sc->d_aux, flat.aux.data(), aux_bytes, hipMemcpyHostToDevice));
-  }
-  RT_HIP(hipMalloc(&sc->d_materials, mat_bytes ? mat_bytes : 32));
-  if (mat_bytes) RT_HIP(hipMemcpy(sc->d_materials, mats.data(), mat_bytes, hipMemcpyHostToDevice));
-
-  sc->dev.nodes = static_cast<const float4*>(sc->d_nodes);
-  sc->dev.spheres = static_cast<const double2*>(sc->d_spheres);
-  sc->dev.aux = static_cast<const double2*>(sc->d_aux);
-  sc->dev.materials = static_cast<const double2*>(sc->d_materials);
-  sc->dev.n_nodes = (uint32_t)n_dev_nodes;
-  sc->dev.n_spheres = (uint32_t)n;
-  sc->dev.n_materials = (uint32_t)nm;
-  sc->dev.n_nodes_lds = n_nodes_lds;
-  sc->dev.n_spheres_lds = n_sph_lds;
-  sc->dev.n_aux_lds = n_aux_lds;
-  sc->dev.n_materials_lds = n_mat_lds;
-  sc->dev.stack_cap = depth;
-  sc->dev.stack_in_lds = stack_in_lds ? 1u : 0u;
-  sc->dev.root = on_device ? tree.root : flat.root;
-  sc->dev.bound = on_device ? tree.bound : flat.bound;
-  bool single = true;  // the device builder makes one-sphere leaves only
-  if (!on_device) {
-    auto one = [](uint32_t ref) { return !(ref & kRefLeaf) || ref == kRefNone || ((ref >> 24) & 0x7fu) == 1u; };
-    single = one(flat.root);
-    for (const DevNode& nd : flat.nodes) single = single && one(nd.ref0) && one(nd.ref1);
-  }
-  sc->dev.single_leaves = single ? 1u : 0u;
-
+  const Replica& r0 = *sc->reps[0];
   sc->info.n_spheres = n;
   sc->info.n_nodes = on_device ? 2 * n - 1 : sc->host.nodes.size();
   sc->info.n_device_nodes = n_dev_nodes;
-  sc->info.depth = on_device ? tree.depth : sc->host.depth;
+  sc->info.depth = on_device ? tree_depth : sc->host.depth;
   sc->info.builder = on_device ? RT_BUILD_DEVICE_LBVH : RT_BUILD_HOST_SAH;
-  sc->info.n_nodes_in_lds = n_nodes_lds;
-  sc->info.spheres_in_lds = (n_sph_lds ? 1u : 0u) | (n_aux_lds ? 2u : 0u) | (n_mat_lds ? 4u : 0u);
-  sc->info.device = (uint32_t)sc->device;
-  sc->info.device_bytes = node_bytes + sph_bytes + aux_bytes + mat_bytes;
-  sc->info.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-  sc->info.lds_bytes = tree_lds_bytes(sc->dev);
+  sc->info.n_nodes_in_lds = r0.dev.n_nodes_lds;
+  sc->info.spheres_in_lds = (r0.dev.n_spheres_lds ? 1u : 0u) | (r0.dev.n_aux_lds ? 2u : 0u) | (r0.dev.n_materials_lds ? 4u : 0u);
+  sc->info.device = (uint32_t)r0.device;
+  sc->info.device_bytes = n_dev_nodes * sizeof(DevNode) + n * sizeof(DevSphere) + n * sizeof(DevSphereAux) + nm * 32;
+  sc->info.build_ms = build_ms;
+  sc->info.lds_bytes = tree_lds_bytes(r0.dev);
+  sc->info.n_devices = (uint32_t)R;
 
-  cleanup.s = nullptr;
-  *out = sc;
+  *out = sc.release();
   return RT_OK;
 }
 
-int rt_scene_destroy(rt_scene* sc) {
-  if (!sc) return RT_OK;
-  DeviceGuard g(sc->device);
-  if (sc->d_nodes) (void)hipFree(sc->d_nodes);
-  if (sc->d_spheres) (void)hipFree(sc->d_spheres);
-  if (sc->d_aux) (void)hipFree(sc->d_aux);
-  if (sc->d_materials) (void)hipFree(sc->d_materials);
-  delete sc;
+// ------------------------------------------------------------- render core ----
+// How a call's sample range is cut into chunks.  A unit of work is one pixel's samples of one chunk, and
+// the lanes of a wave share out the units of one 8x8 tile, so a lane with a cheap pixel takes
+// more of them.  Enough chunks to keep lanes busy (about chunk_spp samples each, at most 16),
+// more when the rectangle has few pixels, fewer when the partial sums would not fit in `limit` bytes.
+// A function of the request only (sample count and the pixels of the whole rectangle): every shard of a
+// rectangle is cut the same way, so a pixel's sum does not depend on how its frame was shared out.
+struct ChunkPlan {
+  uint32_t n_chunks, chunk_spp;
+};
+ChunkPlan plan_chunks(uint32_t spp, uint64_t pixels, uint64_t limit) {
+  const uint64_t target = g_target_units.load();
+  uint64_t want = std::max<uint64_t>(std::min<uint64_t>(16, spp / std::max<uint32_t>(1, g_chunk_spp.load())), (target + pixels - 1) / pixels);
+  want = std::min<uint64_t>(want, std::max<uint64_t>(1, limit / (pixels * 24)));
+  uint32_t n_chunks = (uint32_t)std::min<uint64_t>(spp, std::max<uint64_t>(1, want));
+  const uint32_t chunk_spp = (spp + n_chunks - 1) / n_chunks;
+  n_chunks = (spp + chunk_spp - 1) / chunk_spp;
+  return ChunkPlan{n_chunks, chunk_spp};
+}
+
+uint32_t shard_tile_rows(const rt_shard& sh) {  // tile rows (8 pixel rows) of the rectangle that belong to the shard
+  const uint32_t all = (sh.rect.y1 - sh.rect.y0 + 7) / 8;
+  return sh.row_first < all ? (all - sh.row_first + sh.row_stride - 1) / sh.row_stride : 0;
+}
+
+int check_shard(const CameraDev& cam, const rt_shard& sh, const char* who) {
+  const rt_rect& r = sh.rect;
+  if (r.x1 > cam.width || r.y1 > cam.height || r.x0 > r.x1 || r.y0 > r.y1) return fail(RT_ERR_INVALID, std::string(who) + ": tile outside the image");
+  if (sh.spp_end < sh.spp_begin) return fail(RT_ERR_INVALID, std::string(who) + ": spp_end < spp_begin");
+  if (sh.row_stride == 0 || sh.row_first >= sh.row_stride) return fail(RT_ERR_INVALID, std::string(who) + ": row_first must be below row_stride");
+  if (cam.width > 0xffffu || cam.height > 0xffffu) return fail(RT_ERR_LIMIT, std::string(who) + ": images larger than 65535 pixels on a side are not supported");
   return RT_OK;
+}
+
+// Takes a workspace from the replica's pool (or makes one) and grows it to the call's needs.
+int acquire_workspace(Replica& rp, size_t partial_bytes, size_t gstack_bytes, std::unique_ptr<Workspace>* out) {
+  std::unique_ptr<Workspace> ws;
+  {
+    std::lock_guard<std::mutex> lock(rp.pool_mu);
+    if (!rp.idle.empty()) {
+      ws = std::move(rp.idle.back());
+      rp.idle.pop_back();
+    }
+  }
+  if (!ws) {
+    ws.reset(new Workspace());
+    RT_HIP(hipMalloc((void**)&ws->counters, kRenderCounters * 8));
+    RT_HIP(hipEventCreate(&ws->ev0));
+    RT_HIP(hipEventCreate(&ws->ev1));
+  }
+  RT_HIP(grow_device((void**)&ws->partial, &ws->partial_cap, partial_bytes));
+  RT_HIP(grow_device((void**)&ws->gstack, &ws->gstack_cap, gstack_bytes));
+  *out = std::move(ws);
+  return RT_OK;
+}
+void release_workspace(Replica& rp, std::unique_ptr<Workspace> ws) {
+  std::lock_guard<std::mutex> lock(rp.pool_mu);
+  if (rp.idle.size() < 4) rp.idle.push_back(std::move(ws));
+}
+
+struct Launch {  // what enqueue_render worked out, for the caller to size the workspace and to fill the stats
+  RenderParams P;
+  int blocks = 0;
+  size_t partial_bytes = 0, gstack_bytes = 0;
+  uint64_t samples = 0;
+  bool nothing = false;  // no pixel, no sample or max_depth 0: no launch
+};
+
+// Everything about a launch that depends on the request only.
+int plan_render(const Replica& rp, const CameraDev& cam, uint64_t seed, const rt_shard& sh, uint64_t workspace_limit, Launch* L) {
+  RenderParams& P = L->P;
+  P = RenderParams{};
+  P.cam = cam;
+  const rt_rect& r = sh.rect;
+  const uint32_t tw = r.x1 - r.x0, th = r.y1 - r.y0, spp = sh.spp_end - sh.spp_begin;
+  const uint32_t rows = shard_tile_rows(sh);
+  // pixels of the shard: whole tile rows, clipped at the rectangle's last row
+  uint64_t shard_pixel_rows = 0;
+  for (uint32_t k = 0; k < rows; ++k) {
+    const uint32_t first = (k * sh.row_stride + sh.row_first) * 8u;
+    shard_pixel_rows += std::min(8u, th - first);
+  }
+  L->samples = (uint64_t)tw * shard_pixel_rows * spp;
+  if (tw == 0 || rows == 0 || spp == 0 || cam.max_depth == 0) {  // max_depth 0: every sample is black (src/camera.rs:99-101)
+    L->nothing = true;
+    return RT_OK;
+  }
+  const ChunkPlan plan = plan_chunks(spp, (uint64_t)tw * th, workspace_limit);
+  P.sc = rp.dev;
+  P.x0 = r.x0;
+  P.y0 = r.y0;
+  P.x1 = r.x1;
+  P.y1 = r.y1;
+  P.row_first = sh.row_first;
+  P.row_stride = sh.row_stride;
+  P.local_rows = rows * 8u;
+  P.tiles_x = (tw + 7) / 8;
+  P.n_tiles = P.tiles_x * rows;
+  P.n_chunks = plan.n_chunks;
+  P.chunk_spp = plan.chunk_spp;
+  P.spp_begin = sh.spp_begin;
+  P.spp_end = sh.spp_end;
+  P.seed_lo = (uint32_t)seed;
+  P.seed_hi = (uint32_t)(seed >> 32);
+  const uint64_t n_items = (uint64_t)P.n_tiles * plan.n_chunks;
+  // the unit counter is read as 32 bits and every lane overshoots it by one at the end
+  if (n_items * 64 >= 0xfff00000ull) return fail(RT_ERR_LIMIT, "rt_render: too many work units; render a smaller tile or sample range");
+  P.n_units = (uint32_t)(n_items * 64);
+  // A wave takes some chunks of one tile at a time: all of them when there are many tiles per wave,
+  // fewer when there are not, so that every wave gets about batches_per_wave batches.
+  const uint64_t n_waves = (uint64_t)rp.num_cus * (kWorkgroup / 64);
+  P.batch_chunks = (uint32_t)std::min<uint64_t>(plan.n_chunks, std::max<uint64_t>(1, n_items / (g_batches_per_wave.load() * n_waves)));
+  P.batches_per_tile = (plan.n_chunks + P.batch_chunks - 1) / P.batch_chunks;
+  P.n_batches = P.n_tiles * P.batches_per_tile;
+  P.direct = plan.n_chunks == 1 ? 1u : 0u;
+  P.inner_min = g_inner_min.load();
+  P.both_min = g_both_min.load();
+  P.leaf_min = g_leaf_min.load();
+  if (!P.sc.stack_in_lds) {
+    P.sc.gstack_stride = (uint32_t)rp.num_cus * kWorkgroup;
+    L->gstack_bytes = (size_t)P.sc.gstack_stride * P.sc.stack_cap * 4;
+  }
+  L->partial_bytes = P.direct ? 0 : (size_t)plan.n_chunks * tw * P.local_rows * 24;
+  // One persistent workgroup per CU (fewer if there is less work than that).
+  L->blocks = rp.num_cus;
+  const uint64_t wgs_needed = (n_items + (kWorkgroup / 64) - 1) / (kWorkgroup / 64);
+  if ((uint64_t)L->blocks > wgs_needed) L->blocks = (int)wgs_needed;
+  return RT_OK;
+}
+
+// Enqueues the launch on `stream` with the workspace given (large enough, on the current device).
+// Returns the number of kernels launched in *launches.
+int enqueue_render(Launch& L, Workspace& ws, double* out_dev, hipStream_t stream, bool profile, uint32_t* launches) {
+  RenderParams& P = L.P;
+  RT_HIP(hipMemsetAsync(ws.counters, 0, kRenderCounters * 8, stream));
+  P.counters = ws.counters;
+  P.sc.gstack = ws.gstack;
+  P.out = P.direct ? out_dev : ws.partial;
+  if (ws.ev0) RT_HIP(hipEventRecord(ws.ev0, stream));
+  RT_HIP(launch_render(P, L.blocks, profile, stream));
+  *launches = 1;
+  if (!P.direct) {
+    RT_HIP(launch_reduce_chunks(ws.partial, out_dev, P.n_chunks, P.x0, P.y0, P.y1, P.x1 - P.x0, P.local_rows, P.row_first, P.row_stride, P.cam.width,
+                                stream));
+    ++*launches;
+  }
+  if (ws.ev1) RT_HIP(hipEventRecord(ws.ev1, stream));
+  return RT_OK;
+}
+
+// After the stream has drained: the launch's counters into the caller's stats.
+int read_stats(const Launch& L, const Workspace& ws, uint32_t launches, bool profile, rt_render_stats* stats) {
+  unsigned long long c[kRenderCounters];
+  RT_HIP(hipMemcpy(c, ws.counters, sizeof(c), hipMemcpyDeviceToHost));
+  float ms = 0.0f;
+  if (ws.ev0 && ws.ev1) RT_HIP(hipEventElapsedTime(&ms, ws.ev0, ws.ev1));
+  stats->rays = c[1];
+  stats->samples = c[2];
+  stats->kernel_ms = ms;
+  stats->launches = launches;
+  stats->node_steps = c[3];
+  stats->sphere_tests = c[4];
+  if (profile) {
+    if (c[5] + c[7] + c[9] + c[11] == 0) {
+      std::fprintf(stderr, "rt profile: this scene's kernel variant (leaves of several spheres, or stacks in global memory) has no instrumented form\n");
+      return RT_OK;
+    }
+    const char* names[4] = {"camera", "inner", "leaf", "shade"};  // BLK_* order
+    for (int k = 0; k < 4; ++k)
+      std::fprintf(stderr, "rt profile: %-6s runs %llu mean active lanes %.1f cycles/run %.0f share of wave time %.3f\n", names[k],
+                   c[5 + 2 * k], c[5 + 2 * k] ? (double)c[6 + 2 * k] / (double)c[5 + 2 * k] : 0.0,
+                   c[5 + 2 * k] ? (double)c[13 + k] / (double)c[5 + 2 * k] : 0.0, c[17] ? (double)c[13 + k] / (double)c[17] : 0.0);
+    // Every wave is busy for (nearly) the whole launch, so stamped cycles / (waves x time) is the stamp clock's rate.
+    std::fprintf(stderr, "rt profile: kernel %.2f ms, %d waves, stamped cycles per wave-second %.3f GHz\n", ms, L.blocks * (int)(kWorkgroup / 64),
+                 (double)c[17] / (L.blocks * (double)(kWorkgroup / 64)) / (ms * 1e-3) / 1e9);
+  }
+  return RT_OK;
+}
+
+// One shard on one replica, start to finish: the body of the single-device render entry points and
+// of each device's share of a multi-device call.  The replica's device must be current.
+int render_shard(Replica& rp, const CameraDev& cam, uint64_t seed, const rt_shard& sh, double* out_dev, hipStream_t stream,
+                 rt_render_stats* stats) {
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  Launch L;
+  int rc = plan_render(rp, cam, seed, sh, kWorkspaceLimit, &L);
+  if (rc) return rc;
+  if (L.nothing) {
+    if (stats && cam.max_depth == 0) stats->samples = L.samples;
+    return RT_OK;
+  }
+  std::unique_ptr<Workspace> ws;
+  rc = acquire_workspace(rp, L.partial_bytes, L.gstack_bytes, &ws);
+  if (rc) return rc;
+  const bool profile = std::getenv("RT_PROFILE_BLOCKS") != nullptr;
+  uint32_t launches = 0;
+  rc = enqueue_render(L, *ws, out_dev, stream, profile, &launches);
+  // The workspace goes back to the pool when this function returns, so the stream must have drained by then.
+  hipError_t e = hipStreamSynchronize(stream);
+  if (rc == RT_OK && e != hipSuccess) rc = fail(RT_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+  if (rc == RT_OK && stats) rc = read_stats(L, *ws, launches, profile, stats);
+  if (rc == RT_OK) release_workspace(rp, std::move(ws));  // after a failure the workspace is dropped, not reused
+  return rc;
+}
+
+void partition_request(uint32_t partition, uint32_t n, const rt_rect& r, uint32_t s0, uint32_t s1, rt_shard* out) {
+  const uint32_t spp = s1 - s0, base = spp / n, extra = spp % n;
+  uint32_t s = s0;
+  for (uint32_t g = 0; g < n; ++g) {
+    rt_shard& sh = out[g];
+    sh.rect = r;
+    if (partition == RT_PARTITION_TILES) {  // tile rows dealt round-robin: cheap sky rows and costly ground rows mix on every device
+      sh.row_first = g;
+      sh.row_stride = n;
+      sh.spp_begin = s0;
+      sh.spp_end = s1;
+    } else {  // contiguous sample ranges, sizes differing by at most one
+      sh.row_first = 0;
+      sh.row_stride = 1;
+      sh.spp_begin = s;
+      s += base + (g < extra ? 1u : 0u);
+      sh.spp_end = s;
+    }
+  }
+}
+
+// Runs job(g) for g in [0, n) on one host thread each (the calling thread takes g = 0) and returns the first
+// failure's code; a job's error text is handed over to the calling thread.  Where a thread cannot be
+// created the job runs on the calling thread.
+template <class F>
+int for_each_replica(size_t n, F job) {
+  std::vector<int> rc(n, RT_OK);
+  std::vector<std::string> msg(n);
+  auto run = [&](size_t g) {
+    rc[g] = guarded("rt_render_multi", [&]() { return job(g); });
+    if (rc[g]) msg[g] = g_error;
+  };
+  std::vector<std::thread> th;
+  th.reserve(n);
+  std::vector<size_t> inline_jobs;
+  for (size_t g = 1; g < n; ++g) {
+    try {
+      th.emplace_back(run, g);
+    } catch (const std::system_error&) {
+      inline_jobs.push_back(g);
+    }
+  }
+  run(0);
+  for (size_t g : inline_jobs) run(g);
+  for (auto& t : th) t.join();
+  for (size_t g = 0; g < n; ++g)
+    if (rc[g]) return fail(rc[g], msg[g]);
+  return RT_OK;
+}
+
+// Every replica renders its shard into its own zeroed frame (rp.frame, whole image).  tiles: afterwards each
+// replica's frame holds its tile rows.  samples: afterwards the frames are summed, in replica order, into
+// replica 0's frame.  The caller holds sc->multi_mu.
+int render_replicas(rt_scene* sc, const CameraDev& cam, uint64_t seed, uint32_t partition, const rt_rect& r, uint32_t s0, uint32_t s1,
+                    std::vector<rt_shard>* shards_out, rt_render_stats* stats) {
+  const size_t R = sc->reps.size();
+  std::vector<rt_shard> shards(R);
+  partition_request(partition, (uint32_t)R, r, s0, s1, shards.data());
+  for (const rt_shard& sh : shards) {
+    int rc = check_shard(cam, sh, "rt_render_multi");
+    if (rc) return rc;
+  }
+  const size_t frame_bytes = (size_t)cam.width * cam.height * 24;
+  std::vector<rt_render_stats> st(R);
+  int rc = for_each_replica(R, [&](size_t g) -> int {
+    Replica& rp = *sc->reps[g];
+    DeviceGuard dg(rp.device);
+    RT_HIP(dg.status);
+    if (!rp.stream) RT_HIP(hipStreamCreateWithFlags(&rp.stream, hipStreamNonBlocking));
+    RT_HIP(grow_device((void**)&rp.frame, &rp.frame_cap, frame_bytes));
+    RT_HIP(hipMemsetAsync(rp.frame, 0, frame_bytes, rp.stream));
+    return render_shard(rp, cam, seed, shards[g], rp.frame, rp.stream, &st[g]);
+  });
+  if (rc) return rc;
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    for (const rt_render_stats& s : st) {
+      stats->rays += s.rays;
+      stats->samples += s.samples;
+      stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms);  // the devices run side by side
+      stats->launches += s.launches;
+      stats->node_steps += s.node_steps;
+      stats->sphere_tests += s.sphere_tests;
+    }
+  }
+  if (partition == RT_PARTITION_SAMPLES && R > 1) {
+    const size_t n_values = (size_t)cam.width * cam.height * 3;
+    bool all_peers = !g_force_staged_sum.load();
+    for (size_t a = 0; a < R && all_peers; ++a)
+      for (size_t b = 0; b < R; ++b) all_peers = all_peers && sc->peer[a][b];
+    if (all_peers) {
+      // Every device reads its slice of all frames over its own links and writes the slice's sum into replica 0's
+      // frame: the traffic is spread over all point-to-point links instead of converging on one device.
+      // (Replica 0's own contribution is already in place: the others are added to it in replica order.)
+      std::vector<const double*> src;
+      for (size_t g = 1; g < R; ++g) src.push_back(sc->reps[g]->frame);
+      rc = for_each_replica(R, [&](size_t g) -> int {
+        Replica& rp = *sc->reps[g];
+        DeviceGuard dg(rp.device);
+        RT_HIP(dg.status);
+        const size_t begin = n_values * g / R, end = n_values * (g + 1) / R;
+        RT_HIP(launch_add_frames(sc->reps[0]->frame, src.data(), (uint32_t)src.size(), begin, end, rp.stream));
+        RT_HIP(hipStreamSynchronize(rp.stream));
+        return RT_OK;
+      });
+      if (rc) return rc;
+    } else {
+      // No peer access: the frames are copied to replica 0's device one after the other and added there.
+      Replica& r0 = *sc->reps[0];
+      DeviceGuard dg(r0.device);
+      RT_HIP(dg.status);
+      RT_HIP(grow_device((void**)&r0.frame2, &r0.frame2_cap, frame_bytes));
+      for (size_t g = 1; g < R; ++g) {
+        RT_HIP(hipMemcpyPeerAsync(r0.frame2, r0.device, sc->reps[g]->frame, sc->reps[g]->device, frame_bytes, r0.stream));
+        const double* one[1] = {r0.frame2};
+        RT_HIP(launch_add_frames(r0.frame, one, 1, 0, n_values, r0.stream));
+      }
+      RT_HIP(hipStreamSynchronize(r0.stream));
+    }
+  }
+  if (shards_out) *shards_out = std::move(shards);
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+int rt_device_count(int* count) {
+  return guarded("rt_device_count", [&]() -> int {
+    if (!count) return fail(RT_ERR_INVALID, "rt_device_count: null argument");
+    RT_HIP(hipGetDeviceCount(count));
+    return RT_OK;
+  });
+}
+int rt_device_set(int ordinal) {
+  return guarded("rt_device_set", [&]() -> int {
+    RT_HIP(hipSetDevice(ordinal));
+    return RT_OK;
+  });
+}
+int rt_device_get(int* ordinal) {
+  return guarded("rt_device_get", [&]() -> int {
+    if (!ordinal) return fail(RT_ERR_INVALID, "rt_device_get: null argument");
+    RT_HIP(hipGetDevice(ordinal));
+    return RT_OK;
+  });
+}
+
+void rt_config_default(rt_config* cfg) {
+  if (cfg) config_default(cfg);
+}
+
+int rt_camera_derive(const rt_config* cfg, rt_camera* out) {
+  return guarded("rt_camera_derive", [&]() -> int {
+    if (!cfg || !out) return fail(RT_ERR_INVALID, "rt_camera_derive: null argument");
+    std::string why = config_check(*cfg);
+    if (!why.empty()) return fail(RT_ERR_INVALID, "rt_camera_derive: " + why);
+    camera_derive(*cfg, out);
+    return RT_OK;
+  });
+}
+
+int rt_scene_create(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, rt_scene** out) {
+  return rt_scene_create_ex(spheres, n, materials, nm, RT_BUILD_HOST_SAH, out);
+}
+
+int rt_scene_create_ex(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, uint32_t builder, rt_scene** out) {
+  return guarded("rt_scene_create", [&]() -> int { return create_scene(spheres, n, materials, nm, builder, nullptr, 0, true, out); });
+}
+
+int rt_scene_create_multi(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, uint32_t builder, const int32_t* devices,
+                          size_t n_devices, rt_scene** out) {
+  return guarded("rt_scene_create_multi",
+                 [&]() -> int { return create_scene(spheres, n, materials, nm, builder, devices, n_devices, false, out); });
+}
+
+int rt_scene_destroy(rt_scene* sc) {
+  return guarded("rt_scene_destroy", [&]() -> int {
+    delete sc;
+    return RT_OK;
+  });
 }
 
 int rt_scene_get_info(const rt_scene* sc, rt_scene_info* out) {
@@ -351,12 +870,13 @@ int rt_scene_bvh_dump(const rt_scene* sc, double* boxes, int32_t* kind, uint64_t
 }
 
 int rt_bvh_build(const rt_sphere* spheres, size_t n, rt_host_bvh** out) {
-  if (!out || (n && !spheres)) return fail(RT_ERR_INVALID, "rt_bvh_build: null argument");
-  rt_host_bvh* b = new (std::nothrow) rt_host_bvh();
-  if (!b) return fail(RT_ERR_LIMIT, "rt_bvh_build: out of host memory");
-  b->bvh = build_bvh(spheres, n);
-  *out = b;
-  return RT_OK;
+  return guarded("rt_bvh_build", [&]() -> int {
+    if (!out || (n && !spheres)) return fail(RT_ERR_INVALID, "rt_bvh_build: null argument");
+    std::unique_ptr<rt_host_bvh> b(new rt_host_bvh());
+    b->bvh = build_bvh(spheres, n);
+    *out = b.release();
+    return RT_OK;
+  });
 }
 int rt_bvh_destroy(rt_host_bvh* b) {
   delete b;
@@ -377,313 +897,307 @@ int rt_bvh_dump(const rt_host_bvh* b, double* boxes, int32_t* kind, uint64_t* sk
 
 int rt_trace_batch(const rt_scene* sc, const double* org, const double* dir, size_t n, double t_min, double t_max, int32_t* prim,
                    double* t, double* normal, uint8_t* front_face) {
-  if (!sc) return fail(RT_ERR_INVALID, "rt_trace_batch: scene is null");
-  if (n == 0) return RT_OK;
-  if (!org || !dir || !prim || !t || !normal || !front_face) return fail(RT_ERR_INVALID, "rt_trace_batch: null buffer");
-  if (std::isnan(t_min) || std::isnan(t_max)) return fail(RT_ERR_INVALID, "rt_trace_batch: NaN interval");
-  DeviceGuard g(sc->device);
-  RT_HIP(g.status);
-  DevBuf d_org, d_dir, d_prim, d_t, d_n, d_f;
-  RT_HIP(d_org.alloc(n * 24));
-  RT_HIP(d_dir.alloc(n * 24));
-  RT_HIP(d_prim.alloc(n * 4));
-  RT_HIP(d_t.alloc(n * 8));
-  RT_HIP(d_n.alloc(n * 24));
-  RT_HIP(d_f.alloc(n));
-  RT_HIP(hipMemcpy(d_org.p, org, n * 24, hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(d_dir.p, dir, n * 24, hipMemcpyHostToDevice));
-  SceneDev dev = sc->dev;
-  DevBuf gstack;
-  if (!dev.stack_in_lds) {  // a tree too deep for LDS stacks: one column of global memory per thread of the launch
-    const size_t blocks = std::min<size_t>((n + kWorkgroup - 1) / kWorkgroup, (size_t)sc->num_cus);
-    dev.gstack_stride = (uint32_t)(blocks * kWorkgroup);
-    RT_HIP(gstack.alloc((size_t)dev.gstack_stride * dev.stack_cap * 4));
-    dev.gstack = gstack.as<uint32_t>();
-  }
-  RT_HIP(launch_trace_batch(dev, d_org.as<double>(), d_dir.as<double>(), n, t_min, t_max, d_prim.as<int32_t>(), d_t.as<double>(),
-                            d_n.as<double>(), d_f.as<uint8_t>(), nullptr, sc->num_cus, nullptr));
-  RT_HIP(hipDeviceSynchronize());
-  RT_HIP(hipMemcpy(prim, d_prim.p, n * 4, hipMemcpyDeviceToHost));
-  RT_HIP(hipMemcpy(t, d_t.p, n * 8, hipMemcpyDeviceToHost));
-  RT_HIP(hipMemcpy(normal, d_n.p, n * 24, hipMemcpyDeviceToHost));
-  RT_HIP(hipMemcpy(front_face, d_f.p, n, hipMemcpyDeviceToHost));
-  return RT_OK;
+  return guarded("rt_trace_batch", [&]() -> int {
+    if (!sc) return fail(RT_ERR_INVALID, "rt_trace_batch: scene is null");
+    if (n == 0) return RT_OK;
+    if (!org || !dir || !prim || !t || !normal || !front_face) return fail(RT_ERR_INVALID, "rt_trace_batch: null buffer");
+    if (std::isnan(t_min) || std::isnan(t_max)) return fail(RT_ERR_INVALID, "rt_trace_batch: NaN interval");
+    const Replica& rp = *sc->reps[0];
+    DeviceGuard g(rp.device);
+    RT_HIP(g.status);
+    DevBuf d_org, d_dir, d_prim, d_t, d_n, d_f;
+    RT_HIP(d_org.alloc(n * 24));
+    RT_HIP(d_dir.alloc(n * 24));
+    RT_HIP(d_prim.alloc(n * 4));
+    RT_HIP(d_t.alloc(n * 8));
+    RT_HIP(d_n.alloc(n * 24));
+    RT_HIP(d_f.alloc(n));
+    RT_HIP(hipMemcpy(d_org.p, org, n * 24, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(d_dir.p, dir, n * 24, hipMemcpyHostToDevice));
+    SceneDev dev = rp.dev;
+    DevBuf gstack;
+    if (!dev.stack_in_lds) {  // a tree too deep for LDS stacks: one column of global memory per thread of the launch
+      const size_t blocks = std::min<size_t>((n + kWorkgroup - 1) / kWorkgroup, (size_t)rp.num_cus);
+      dev.gstack_stride = (uint32_t)(blocks * kWorkgroup);
+      RT_HIP(gstack.alloc((size_t)dev.gstack_stride * dev.stack_cap * 4));
+      dev.gstack = gstack.as<uint32_t>();
+    }
+    RT_HIP(launch_trace_batch(dev, d_org.as<double>(), d_dir.as<double>(), n, t_min, t_max, d_prim.as<int32_t>(), d_t.as<double>(),
+                              d_n.as<double>(), d_f.as<uint8_t>(), nullptr, rp.num_cus, nullptr));
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(prim, d_prim.p, n * 4, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(t, d_t.p, n * 8, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(normal, d_n.p, n * 24, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(front_face, d_f.p, n, hipMemcpyDeviceToHost));
+    return RT_OK;
+  });
 }
 
 int rt_scatter_batch(const rt_scene* sc, const uint32_t* material, const double* in_dir, const double* p, const double* normal,
                      const uint8_t* front_face, const double* u, size_t n, uint8_t* scattered, double* attenuation, double* out_dir) {
-  if (!sc) return fail(RT_ERR_INVALID, "rt_scatter_batch: scene is null");
-  if (n == 0) return RT_OK;
-  if (!material || !in_dir || !p || !normal || !front_face || !u || !scattered || !attenuation || !out_dir)
-    return fail(RT_ERR_INVALID, "rt_scatter_batch: null buffer");
-  std::vector<uint32_t> tagged(n);  // material index with its type in the top two bits, as the kernels carry it
-  for (size_t i = 0; i < n; ++i) {
-    if (material[i] >= sc->n_materials) return fail(RT_ERR_INVALID, "rt_scatter_batch: material index out of range");
-    tagged[i] = material[i] | ((uint32_t)sc->material_type[material[i]] << 30);
-  }
-  DeviceGuard g(sc->device);
-  RT_HIP(g.status);
-  DevBuf d_m, d_in, d_p, d_n, d_f, d_u, d_s, d_a, d_o;
-  RT_HIP(d_m.alloc(n * 4));
-  RT_HIP(d_in.alloc(n * 24));
-  RT_HIP(d_p.alloc(n * 24));
-  RT_HIP(d_n.alloc(n * 24));
-  RT_HIP(d_f.alloc(n));
-  RT_HIP(d_u.alloc(n * 16));
-  RT_HIP(d_s.alloc(n));
-  RT_HIP(d_a.alloc(n * 24));
-  RT_HIP(d_o.alloc(n * 24));
-  RT_HIP(hipMemcpy(d_m.p, tagged.data(), n * 4, hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(d_in.p, in_dir, n * 24, hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(d_p.p, p, n * 24, hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(d_n.p, normal, n * 24, hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(d_f.p, front_face, n, hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(d_u.p, u, n * 16, hipMemcpyHostToDevice));
-  RT_HIP(launch_scatter_batch(sc->dev, d_m.as<uint32_t>(), d_in.as<double>(), d_p.as<double>(), d_n.as<double>(), d_f.as<uint8_t>(),
-                              d_u.as<double>(), n, d_s.as<uint8_t>(), d_a.as<double>(), d_o.as<double>(), nullptr));
-  RT_HIP(hipDeviceSynchronize());
-  RT_HIP(hipMemcpy(scattered, d_s.p, n, hipMemcpyDeviceToHost));
-  RT_HIP(hipMemcpy(attenuation, d_a.p, n * 24, hipMemcpyDeviceToHost));
-  RT_HIP(hipMemcpy(out_dir, d_o.p, n * 24, hipMemcpyDeviceToHost));
-  return RT_OK;
+  return guarded("rt_scatter_batch", [&]() -> int {
+    if (!sc) return fail(RT_ERR_INVALID, "rt_scatter_batch: scene is null");
+    if (n == 0) return RT_OK;
+    if (!material || !in_dir || !p || !normal || !front_face || !u || !scattered || !attenuation || !out_dir)
+      return fail(RT_ERR_INVALID, "rt_scatter_batch: null buffer");
+    std::vector<uint32_t> tagged(n);  // material index with its type in the top two bits, as the kernels carry it
+    for (size_t i = 0; i < n; ++i) {
+      if (material[i] >= sc->n_materials) return fail(RT_ERR_INVALID, "rt_scatter_batch: material index out of range");
+      tagged[i] = material[i] | ((uint32_t)sc->material_type[material[i]] << 30);
+    }
+    const Replica& rp = *sc->reps[0];
+    DeviceGuard g(rp.device);
+    RT_HIP(g.status);
+    DevBuf d_m, d_in, d_p, d_n, d_f, d_u, d_s, d_a, d_o;
+    RT_HIP(d_m.alloc(n * 4));
+    RT_HIP(d_in.alloc(n * 24));
+    RT_HIP(d_p.alloc(n * 24));
+    RT_HIP(d_n.alloc(n * 24));
+    RT_HIP(d_f.alloc(n));
+    RT_HIP(d_u.alloc(n * 16));
+    RT_HIP(d_s.alloc(n));
+    RT_HIP(d_a.alloc(n * 24));
+    RT_HIP(d_o.alloc(n * 24));
+    RT_HIP(hipMemcpy(d_m.p, tagged.data(), n * 4, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(d_in.p, in_dir, n * 24, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(d_p.p, p, n * 24, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(d_n.p, normal, n * 24, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(d_f.p, front_face, n, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(d_u.p, u, n * 16, hipMemcpyHostToDevice));
+    RT_HIP(launch_scatter_batch(rp.dev, d_m.as<uint32_t>(), d_in.as<double>(), d_p.as<double>(), d_n.as<double>(), d_f.as<uint8_t>(),
+                                d_u.as<double>(), n, d_s.as<uint8_t>(), d_a.as<double>(), d_o.as<double>(), nullptr));
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(scattered, d_s.p, n, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(attenuation, d_a.p, n * 24, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(out_dir, d_o.p, n * 24, hipMemcpyDeviceToHost));
+    return RT_OK;
+  });
 }
 
 int rt_slab_batch(const double* boxes, const double* org, const double* dir, const double* interval, size_t n, uint8_t* hit) {
-  if (n == 0) return RT_OK;
-  if (!boxes || !org || !dir || !interval || !hit) return fail(RT_ERR_INVALID, "rt_slab_batch: null buffer");
-  // Round the boxes outwards to f32 exactly as scene creation does.
-  std::vector<float> fb(8 * n, 0.0f);
-  for (size_t i = 0; i < n; ++i)
-    for (int k = 0; k < 3; ++k) {
-      double lo = boxes[6 * i + k], hi = boxes[6 * i + 3 + k];
-      float fl = (float)lo, fh = (float)hi;
-      if ((double)fl > lo) fl = std::nextafterf(fl, -INFINITY);
-      if ((double)fh < hi) fh = std::nextafterf(fh, INFINITY);
-      fb[8 * i + k] = fl;
-      fb[8 * i + 4 + k] = fh;
-      fb[8 * i + 3] = std::fmax(fb[8 * i + 3], std::fmax(std::fabs(fl), std::fabs(fh)));  // the pad's bound on |coordinate|
-    }
-  DevBuf d_b, d_o, d_d, d_i, d_h;
-  RT_HIP(d_b.alloc(n * 32));
-  RT_HIP(d_o.alloc(n * 24));
-  RT_HIP(d_d.alloc(n * 24));
-  RT_HIP(d_i.alloc(n * 16));
-  RT_HIP(d_h.alloc(n));
-  RT_HIP(hipMemcpy(d_b.p, fb.data(), n * 32, hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(d_o.p, org, n * 24, hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(d_d.p, dir, n * 24, hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(d_i.p, interval, n * 16, hipMemcpyHostToDevice));
-  RT_HIP(launch_slab_batch(d_b.as<float>(), d_o.as<double>(), d_d.as<double>(), d_i.as<double>(), n, d_h.as<uint8_t>(), nullptr));
-  RT_HIP(hipDeviceSynchronize());
-  RT_HIP(hipMemcpy(hit, d_h.p, n, hipMemcpyDeviceToHost));
-  return RT_OK;
+  return guarded("rt_slab_batch", [&]() -> int {
+    if (n == 0) return RT_OK;
+    if (!boxes || !org || !dir || !interval || !hit) return fail(RT_ERR_INVALID, "rt_slab_batch: null buffer");
+    // Round the boxes outwards to f32 exactly as scene creation does.
+    std::vector<float> fb(8 * n, 0.0f);
+    for (size_t i = 0; i < n; ++i)
+      for (int k = 0; k < 3; ++k) {
+        double lo = boxes[6 * i + k], hi = boxes[6 * i + 3 + k];
+        float fl = (float)lo, fh = (float)hi;
+        if ((double)fl > lo) fl = std::nextafterf(fl, -INFINITY);
+        if ((double)fh < hi) fh = std::nextafterf(fh, INFINITY);
+        fb[8 * i + k] = fl;
+        fb[8 * i + 4 + k] = fh;
+        fb[8 * i + 3] = std::fmax(fb[8 * i + 3], std::fmax(std::fabs(fl), std::fabs(fh)));  // the pad's bound on |coordinate|
+      }
+    DevBuf d_b, d_o, d_d, d_i, d_h;
+    RT_HIP(d_b.alloc(n * 32));
+    RT_HIP(d_o.alloc(n * 24));
+    RT_HIP(d_d.alloc(n * 24));
+    RT_HIP(d_i.alloc(n * 16));
+    RT_HIP(d_h.alloc(n));
+    RT_HIP(hipMemcpy(d_b.p, fb.data(), n * 32, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(d_o.p, org, n * 24, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(d_d.p, dir, n * 24, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(d_i.p, interval, n * 16, hipMemcpyHostToDevice));
+    RT_HIP(launch_slab_batch(d_b.as<float>(), d_o.as<double>(), d_d.as<double>(), d_i.as<double>(), n, d_h.as<uint8_t>(), nullptr));
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(hit, d_h.p, n, hipMemcpyDeviceToHost));
+    return RT_OK;
+  });
 }
 
 int rt_primary_rays(const rt_config* cfg, uint64_t seed, const uint32_t* ijs, size_t n, double* org, double* dir) {
-  CameraDev cam;
-  int rc = make_camera_dev(cfg, &cam, "rt_primary_rays");
-  if (rc) return rc;
-  if (n == 0) return RT_OK;
-  if (!ijs || !org || !dir) return fail(RT_ERR_INVALID, "rt_primary_rays: null buffer");
-  DevBuf d_i, d_o, d_d;
-  RT_HIP(d_i.alloc(n * 12));
-  RT_HIP(d_o.alloc(n * 24));
-  RT_HIP(d_d.alloc(n * 24));
-  RT_HIP(hipMemcpy(d_i.p, ijs, n * 12, hipMemcpyHostToDevice));
-  RT_HIP(launch_primary_rays(cam, seed, d_i.as<uint32_t>(), n, d_o.as<double>(), d_d.as<double>(), nullptr));
-  RT_HIP(hipDeviceSynchronize());
-  RT_HIP(hipMemcpy(org, d_o.p, n * 24, hipMemcpyDeviceToHost));
-  RT_HIP(hipMemcpy(dir, d_d.p, n * 24, hipMemcpyDeviceToHost));
-  return RT_OK;
+  return guarded("rt_primary_rays", [&]() -> int {
+    CameraDev cam;
+    int rc = make_camera_dev(cfg, &cam, "rt_primary_rays");
+    if (rc) return rc;
+    if (n == 0) return RT_OK;
+    if (!ijs || !org || !dir) return fail(RT_ERR_INVALID, "rt_primary_rays: null buffer");
+    DevBuf d_i, d_o, d_d;
+    RT_HIP(d_i.alloc(n * 12));
+    RT_HIP(d_o.alloc(n * 24));
+    RT_HIP(d_d.alloc(n * 24));
+    RT_HIP(hipMemcpy(d_i.p, ijs, n * 12, hipMemcpyHostToDevice));
+    RT_HIP(launch_primary_rays(cam, seed, d_i.as<uint32_t>(), n, d_o.as<double>(), d_d.as<double>(), nullptr));
+    RT_HIP(hipDeviceSynchronize());
+    RT_HIP(hipMemcpy(org, d_o.p, n * 24, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(dir, d_d.p, n * 24, hipMemcpyDeviceToHost));
+    return RT_OK;
+  });
+}
+
+int rt_render_shard_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, const rt_shard* shard, double* rgb_sum_dev, void* stream,
+                           rt_render_stats* stats) {
+  return guarded("rt_render", [&]() -> int {
+    if (!sc) return fail(RT_ERR_INVALID, "rt_render: scene is null");
+    if (!rgb_sum_dev) return fail(RT_ERR_INVALID, "rt_render: rgb_sum is null");
+    if (!shard) return fail(RT_ERR_INVALID, "rt_render: shard is null");
+    CameraDev cam;
+    int rc = make_camera_dev(cfg, &cam, "rt_render");
+    if (rc) return rc;
+    rc = check_shard(cam, *shard, "rt_render");
+    if (rc) return rc;
+    Replica& rp = *sc->reps[0];
+    DeviceGuard g(rp.device);
+    RT_HIP(g.status);
+    return render_shard(rp, cam, seed, *shard, rgb_sum_dev, static_cast<hipStream_t>(stream), stats);
+  });
 }
 
 int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile,
-                     double* rgb_sum_dev, void* stream_, rt_render_stats* stats) {
-  if (!sc) return fail(RT_ERR_INVALID, "rt_render: scene is null");
-  if (!rgb_sum_dev) return fail(RT_ERR_INVALID, "rt_render: rgb_sum is null");
-  RenderParams P{};
-  int rc = make_camera_dev(cfg, &P.cam, "rt_render");
+                     double* rgb_sum_dev, void* stream, rt_render_stats* stats) {
+  if (!cfg) return fail(RT_ERR_INVALID, "rt_render: cfg is null");
+  rt_camera c;
+  int rc = rt_camera_derive(cfg, &c);
   if (rc) return rc;
-  if (spp_end < spp_begin) return fail(RT_ERR_INVALID, "rt_render: spp_end < spp_begin");
-  rt_rect r = tile ? *tile : rt_rect{0, 0, P.cam.width, P.cam.height};
-  if (r.x1 > P.cam.width || r.y1 > P.cam.height || r.x0 > r.x1 || r.y0 > r.y1) return fail(RT_ERR_INVALID, "rt_render: tile outside the image");
-  if (stats) std::memset(stats, 0, sizeof(*stats));
-  const uint32_t tw = r.x1 - r.x0, th = r.y1 - r.y0, spp = spp_end - spp_begin;
-  if (tw == 0 || th == 0 || spp == 0) return RT_OK;
-  if (P.cam.max_depth == 0) {  // every sample is black (src/camera.rs:99-101): nothing to add to the frame
-    if (stats) stats->samples = (uint64_t)tw * th * spp;
-    return RT_OK;
-  }
-
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  DeviceGuard g(sc->device);
-  RT_HIP(g.status);
-
-  // The sample range is cut into chunks: a unit of work is one pixel's samples of one chunk, and
-  // the lanes of a wave share out the units of one 8x8 tile, so a lane with a cheap pixel takes
-  // more of them.  Enough chunks to keep lanes busy (about g_chunk_spp samples each, at most 16),
-  // more when the rectangle has few pixels, fewer when the partial sums would not fit in 4 GB.
-  // The count depends on the request only.
-  const uint64_t kTargetLanes = g_target_units;
-  uint64_t pixels = (uint64_t)tw * th;
-  uint64_t want = std::max<uint64_t>(std::min<uint64_t>(16, spp / std::max<uint32_t>(1, g_chunk_spp)), (kTargetLanes + pixels - 1) / pixels);
-  want = std::min<uint64_t>(want, std::max<uint64_t>(1, (4ull << 30) / (pixels * 24)));
-  uint32_t n_chunks = (uint32_t)std::min<uint64_t>(spp, std::max<uint64_t>(1, want));
-  uint32_t chunk_spp = (spp + n_chunks - 1) / n_chunks;
-  n_chunks = (spp + chunk_spp - 1) / chunk_spp;
-
-  P.sc = sc->dev;
-  P.x0 = r.x0;
-  P.y0 = r.y0;
-  P.x1 = r.x1;
-  P.y1 = r.y1;
-  P.tiles_x = (tw + 7) / 8;
-  P.n_tiles = P.tiles_x * ((th + 7) / 8);
-  P.n_chunks = n_chunks;
-  P.chunk_spp = chunk_spp;
-  P.spp_begin = spp_begin;
-  P.spp_end = spp_end;
-  P.seed_lo = (uint32_t)seed;
-  P.seed_hi = (uint32_t)(seed >> 32);
-  uint64_t n_items = (uint64_t)P.n_tiles * n_chunks;
-  // the unit counter is read as 32 bits and every lane overshoots it by one at the end
-  if (n_items * 64 >= 0xfff00000ull) return fail(RT_ERR_LIMIT, "rt_render: too many work units; render a smaller tile or sample range");
-  if (P.cam.width > 0xffffu || P.cam.height > 0xffffu) return fail(RT_ERR_LIMIT, "rt_render: images larger than 65535 pixels on a side are not supported");
-  P.n_units = (uint32_t)(n_items * 64);
-  // A wave takes some chunks of one tile at a time: all of them when there are many tiles per wave,
-  // fewer when there are not, so that every wave gets about g_batches_per_wave batches.
-  const uint64_t n_waves = (uint64_t)sc->num_cus * (kWorkgroup / 64);
-  P.batch_chunks = (uint32_t)std::min<uint64_t>(n_chunks, std::max<uint64_t>(1, n_items / (g_batches_per_wave * n_waves)));
-  P.batches_per_tile = (n_chunks + P.batch_chunks - 1) / P.batch_chunks;
-  P.n_batches = P.n_tiles * P.batches_per_tile;
-  P.direct = n_chunks == 1 ? 1u : 0u;
-  P.inner_min = g_inner_min;
-  P.both_min = g_both_min;
-  P.leaf_min = g_leaf_min;
-
-  DevBuf counters, partial, gstack;
-  if (!P.sc.stack_in_lds) {
-    P.sc.gstack_stride = (uint32_t)sc->num_cus * kWorkgroup;
-    RT_HIP(gstack.alloc((size_t)P.sc.gstack_stride * P.sc.stack_cap * 4));
-    P.sc.gstack = gstack.as<uint32_t>();
-  }
-  RT_HIP(counters.alloc(kRenderCounters * 8));
-  RT_HIP(hipMemsetAsync(counters.p, 0, kRenderCounters * 8, stream));
-  P.counters = counters.as<unsigned long long>();
-  if (P.direct) {
-    P.out = rgb_sum_dev;
-  } else {
-    RT_HIP(partial.alloc((size_t)n_chunks * pixels * 24));
-    P.out = partial.as<double>();
-  }
-
-  // One persistent workgroup per CU (fewer if there is less work than that).
-  int blocks = sc->num_cus;
-  uint64_t wgs_needed = (n_items + (kWorkgroup / 64) - 1) / (kWorkgroup / 64);
-  if ((uint64_t)blocks > wgs_needed) blocks = (int)wgs_needed;
-
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  RT_HIP(hipEventCreate(&ev0));
-  struct EvGuard {
-    hipEvent_t& a;
-    hipEvent_t& b;
-    ~EvGuard() {
-      if (a) (void)hipEventDestroy(a);
-      if (b) (void)hipEventDestroy(b);
-    }
-  } evg{ev0, ev1};
-  RT_HIP(hipEventCreate(&ev1));
-  RT_HIP(hipEventRecord(ev0, stream));
-  const bool profile = std::getenv("RT_PROFILE_BLOCKS") != nullptr;
-  RT_HIP(launch_render(P, blocks, profile, stream));
-  uint32_t launches = 1;
-  if (!P.direct) {
-    RT_HIP(launch_reduce_chunks(partial.as<double>(), rgb_sum_dev, n_chunks, r.x0, r.y0, tw, th, P.cam.width, stream));
-    ++launches;
-  }
-  RT_HIP(hipEventRecord(ev1, stream));
-
-  // The workspace is freed when this function returns, so the stream must have drained by then.
-  RT_HIP(hipStreamSynchronize(stream));
-  if (stats) {
-    unsigned long long c[kRenderCounters];
-    RT_HIP(hipMemcpy(c, counters.p, sizeof(c), hipMemcpyDeviceToHost));
-    float ms = 0.0f;
-    RT_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-    stats->rays = c[1];
-    stats->samples = c[2];
-    stats->kernel_ms = ms;
-    stats->launches = launches;
-    stats->node_steps = c[3];
-    stats->sphere_tests = c[4];
-    if (profile) {
-      const char* names[4] = {"camera", "inner", "leaf", "shade"};  // BLK_* order
-      for (int k = 0; k < 4; ++k)
-        std::fprintf(stderr, "rt profile: %-6s runs %llu mean active lanes %.1f cycles/run %.0f share of wave time %.3f\n", names[k],
-                     c[5 + 2 * k], c[5 + 2 * k] ? (double)c[6 + 2 * k] / (double)c[5 + 2 * k] : 0.0,
-                     c[5 + 2 * k] ? (double)c[13 + k] / (double)c[5 + 2 * k] : 0.0, c[17] ? (double)c[13 + k] / (double)c[17] : 0.0);
-      // Every wave is busy for (nearly) the whole launch, so stamped cycles / (waves x time) is the stamp clock's rate.
-      std::fprintf(stderr, "rt profile: kernel %.2f ms, %d waves, stamped cycles per wave-second %.3f GHz\n", ms, blocks * (int)(kWorkgroup / 64),
-                   (double)c[17] / (blocks * (double)(kWorkgroup / 64)) / (ms * 1e-3) / 1e9);
-    }
-  }
-  return RT_OK;
+  rt_shard sh{tile ? *tile : rt_rect{0, 0, cfg->image_width, c.image_height}, 0, 1, spp_begin, spp_end};
+  return rt_render_shard_device(sc, cfg, seed, &sh, rgb_sum_dev, stream, stats);
 }
 
 int rt_render(const rt_scene* sc, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile,
               double* rgb_sum, rt_render_stats* stats) {
-  if (!sc) return fail(RT_ERR_INVALID, "rt_render: scene is null");
-  if (!rgb_sum) return fail(RT_ERR_INVALID, "rt_render: rgb_sum is null");
-  CameraDev cam;
-  int rc = make_camera_dev(cfg, &cam, "rt_render");
-  if (rc) return rc;
-  DeviceGuard g(sc->device);
-  RT_HIP(g.status);
-  const size_t n = (size_t)cam.width * cam.height * 3;
-  DevBuf img;
-  RT_HIP(img.alloc(n * 8));
-  RT_HIP(hipMemset(img.p, 0, n * 8));
-  rc = rt_render_device(sc, cfg, seed, spp_begin, spp_end, tile, img.as<double>(), nullptr, stats);
-  if (rc) return rc;
-  std::vector<double> host(n);
-  RT_HIP(hipMemcpy(host.data(), img.p, n * 8, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < n; ++i) rgb_sum[i] += host[i];
-  return RT_OK;
+  return guarded("rt_render", [&]() -> int {
+    if (!sc) return fail(RT_ERR_INVALID, "rt_render: scene is null");
+    if (!rgb_sum) return fail(RT_ERR_INVALID, "rt_render: rgb_sum is null");
+    CameraDev cam;
+    int rc = make_camera_dev(cfg, &cam, "rt_render");
+    if (rc) return rc;
+    DeviceGuard g(sc->reps[0]->device);
+    RT_HIP(g.status);
+    const size_t n = (size_t)cam.width * cam.height * 3;
+    DevBuf img;
+    RT_HIP(img.alloc(n * 8));
+    RT_HIP(hipMemset(img.p, 0, n * 8));
+    rc = rt_render_device(sc, cfg, seed, spp_begin, spp_end, tile, img.as<double>(), nullptr, stats);
+    if (rc) return rc;
+    std::vector<double> host(n);
+    RT_HIP(hipMemcpy(host.data(), img.p, n * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) rgb_sum[i] += host[i];
+    return RT_OK;
+  });
+}
+
+int rt_partition(const rt_config* cfg, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile, uint32_t partition, uint32_t n_devices,
+                 rt_shard* shards) {
+  return guarded("rt_partition", [&]() -> int {
+    if (!shards) return fail(RT_ERR_INVALID, "rt_partition: shards is null");
+    if (partition > RT_PARTITION_SAMPLES) return fail(RT_ERR_INVALID, "rt_partition: unknown partition");
+    if (n_devices == 0) return fail(RT_ERR_INVALID, "rt_partition: n_devices is 0");
+    CameraDev cam;
+    int rc = make_camera_dev(cfg, &cam, "rt_partition");
+    if (rc) return rc;
+    const rt_rect r = tile ? *tile : rt_rect{0, 0, cam.width, cam.height};
+    const rt_shard whole{r, 0, 1, spp_begin, spp_end};
+    rc = check_shard(cam, whole, "rt_partition");
+    if (rc) return rc;
+    partition_request(partition, n_devices, r, spp_begin, spp_end, shards);
+    return RT_OK;
+  });
+}
+
+int rt_render_multi(const rt_scene* sc_, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile,
+                    uint32_t partition, double* rgb_sum, rt_render_stats* stats) {
+  return guarded("rt_render_multi", [&]() -> int {
+    rt_scene* sc = const_cast<rt_scene*>(sc_);  // the replicas' frame buffers are scratch state behind multi_mu
+    if (!sc) return fail(RT_ERR_INVALID, "rt_render_multi: scene is null");
+    if (!rgb_sum) return fail(RT_ERR_INVALID, "rt_render_multi: rgb_sum is null");
+    if (partition > RT_PARTITION_SAMPLES) return fail(RT_ERR_INVALID, "rt_render_multi: unknown partition");
+    CameraDev cam;
+    int rc = make_camera_dev(cfg, &cam, "rt_render_multi");
+    if (rc) return rc;
+    const rt_rect r = tile ? *tile : rt_rect{0, 0, cam.width, cam.height};
+    const rt_shard whole{r, 0, 1, spp_begin, spp_end};
+    rc = check_shard(cam, whole, "rt_render_multi");
+    if (rc) return rc;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    std::lock_guard<std::mutex> lock(sc->multi_mu);
+    std::vector<rt_shard> shards;
+    rc = render_replicas(sc, cam, seed, partition, r, spp_begin, spp_end, &shards, stats);
+    if (rc) return rc;
+    const uint32_t tw = r.x1 - r.x0;
+    if (tw == 0 || r.y1 == r.y0) return RT_OK;
+    const size_t row_bytes = (size_t)cam.width * 24;
+    // Back to the host through pinned memory, each replica its own rows, and added into the caller's frame.
+    const size_t R = partition == RT_PARTITION_TILES ? sc->reps.size() : 1;  // samples: replica 0 holds the sum
+    return for_each_replica(R, [&](size_t g) -> int {
+      Replica& rp = *sc->reps[g];
+      DeviceGuard dg(rp.device);
+      RT_HIP(dg.status);
+      const rt_shard& sh = partition == RT_PARTITION_TILES ? shards[g] : whole;
+      const uint32_t rows = shard_tile_rows(sh);
+      size_t need = 0;
+      for (uint32_t k = 0; k < rows; ++k) need += std::min(8u, (r.y1 - r.y0) - (k * sh.row_stride + sh.row_first) * 8u) * row_bytes;
+      if (need > rp.pinned_cap) {
+        if (rp.pinned) (void)hipHostFree(rp.pinned);
+        rp.pinned = nullptr;
+        rp.pinned_cap = 0;
+        RT_HIP(hipHostMalloc(&rp.pinned, need, hipHostMallocDefault));
+        rp.pinned_cap = need;
+      }
+      char* stage = static_cast<char*>(rp.pinned);
+      size_t at = 0;
+      for (uint32_t k = 0; k < rows; ++k) {  // one copy per band of consecutive rows
+        const uint32_t y = r.y0 + (k * sh.row_stride + sh.row_first) * 8u, nrow = std::min(8u, r.y1 - y);
+        RT_HIP(hipMemcpyAsync(stage + at, rp.frame + (size_t)y * cam.width * 3, nrow * row_bytes, hipMemcpyDeviceToHost, rp.stream));
+        at += nrow * row_bytes;
+      }
+      RT_HIP(hipStreamSynchronize(rp.stream));
+      at = 0;
+      for (uint32_t k = 0; k < rows; ++k) {
+        const uint32_t y = r.y0 + (k * sh.row_stride + sh.row_first) * 8u, nrow = std::min(8u, r.y1 - y);
+        for (uint32_t dy = 0; dy < nrow; ++dy) {
+          const double* src = reinterpret_cast<const double*>(stage + at + dy * row_bytes) + 3 * (size_t)r.x0;
+          double* dst = rgb_sum + 3 * ((size_t)(y + dy) * cam.width + r.x0);
+          for (size_t i = 0; i < 3 * (size_t)tw; ++i) dst[i] += src[i];
+        }
+        at += nrow * row_bytes;
+      }
+      return RT_OK;
+    });
+  });
 }
 
 int rt_debug_set(const char* name, double value) {
-  if (!name) return fail(RT_ERR_INVALID, "rt_debug_set: name is null");
-  if (std::strcmp(name, "inner_min") == 0) {
-    g_inner_min = (uint32_t)value;
-    return RT_OK;
-  }
-  if (std::strcmp(name, "leaf_min") == 0) {
-    g_leaf_min = (uint32_t)value;
-    return RT_OK;
-  }
-  if (std::strcmp(name, "batches_per_wave") == 0) {
-    g_batches_per_wave = std::max<uint64_t>(1, (uint64_t)value);
-    return RT_OK;
-  }
-  if (std::strcmp(name, "both_min") == 0) {
-    g_both_min = (uint32_t)value;
-    return RT_OK;
-  }
-  if (std::strcmp(name, "force_global_stack") == 0) {
-    g_force_global_stack = value != 0.0;
-    return RT_OK;
-  }
-  if (std::strcmp(name, "target_units") == 0) {
-    if (!(value >= 1.0 && value <= 1e12)) return fail(RT_ERR_INVALID, "rt_debug_set: target_units must be in 1 .. 1e12");
-    g_target_units = (uint64_t)value;
-    return RT_OK;
-  }
-  if (std::strcmp(name, "chunk_spp") == 0) {
-    if (!(value >= 1.0 && value <= 1e9)) return fail(RT_ERR_INVALID, "rt_debug_set: chunk_spp must be in 1 .. 1e9");
-    g_chunk_spp = (uint32_t)value;
-    return RT_OK;
-  }
-  return fail(RT_ERR_INVALID, std::string("rt_debug_set: unknown tunable ") + name);
+  return guarded("rt_debug_set", [&]() -> int {
+    if (!name) return fail(RT_ERR_INVALID, "rt_debug_set: name is null");
+    const std::string key(name);
+    // A wave's traversal loop ends when fewer than inner_min lanes want the inner block and fewer than leaf_min
+    // the leaf block: with a threshold of 0 it would never end.
+    auto lanes = [&](std::atomic<uint32_t>& knob, double lo) -> int {
+      if (!(value >= lo && value <= 64.0) || value != std::floor(value))
+        return fail(RT_ERR_INVALID, "rt_debug_set: " + key + " must be a whole number in " + std::to_string((int)lo) + " .. 64");
+      knob.store((uint32_t)value);
+      return RT_OK;
+    };
+    if (key == "inner_min") return lanes(g_inner_min, 1.0);
+    if (key == "leaf_min") return lanes(g_leaf_min, 1.0);
+    if (key == "both_min") return lanes(g_both_min, 0.0);
+    if (key == "batches_per_wave") {
+      if (!(value >= 1.0 && value <= 1e9)) return fail(RT_ERR_INVALID, "rt_debug_set: batches_per_wave must be in 1 .. 1e9");
+      g_batches_per_wave.store((uint64_t)value);
+      return RT_OK;
+    }
+    if (key == "force_global_stack") {
+      g_force_global_stack.store(value != 0.0);
+      return RT_OK;
+    }
+    if (key == "force_staged_sum") {
+      g_force_staged_sum.store(value != 0.0);
+      return RT_OK;
+    }
+    if (key == "target_units") {
+      if (!(value >= 1.0 && value <= 1e12)) return fail(RT_ERR_INVALID, "rt_debug_set: target_units must be in 1 .. 1e12");
+      g_target_units.store((uint64_t)value);
+      return RT_OK;
+    }
+    if (key == "chunk_spp") {
+      if (!(value >= 1.0 && value <= 1e9)) return fail(RT_ERR_INVALID, "rt_debug_set: chunk_spp must be in 1 .. 1e9");
+      g_chunk_spp.store((uint32_t)value);
+      return RT_OK;
+    }
+    return fail(RT_ERR_INVALID, "rt_debug_set: unknown tunable " + key);
+  });
 }
 
 int rt_quantise(const double* rgb_sum, size_t n_pixels, uint64_t spp, uint8_t* out) {
@@ -693,46 +1207,73 @@ int rt_quantise(const double* rgb_sum, size_t n_pixels, uint64_t spp, uint8_t* o
 }
 
 int rt_quantise_device(const double* rgb_sum_dev, size_t n_pixels, uint64_t spp, uint8_t* out_dev, void* stream) {
-  if (n_pixels && (!rgb_sum_dev || !out_dev)) return fail(RT_ERR_INVALID, "rt_quantise_device: null buffer");
-  if (((uintptr_t)rgb_sum_dev & 15) || ((uintptr_t)out_dev & 1)) return fail(RT_ERR_INVALID, "rt_quantise_device: rgb_sum must be 16-byte and out 2-byte aligned");
-  if (spp == 0) return fail(RT_ERR_INVALID, "rt_quantise_device: samples_per_pixel is 0");
-  RT_HIP(launch_quantise(rgb_sum_dev, 3 * n_pixels, spp, out_dev, (hipStream_t)stream));
-  RT_HIP(hipStreamSynchronize((hipStream_t)stream));
-  return RT_OK;
+  return guarded("rt_quantise_device", [&]() -> int {
+    if (n_pixels && (!rgb_sum_dev || !out_dev)) return fail(RT_ERR_INVALID, "rt_quantise_device: null buffer");
+    if (((uintptr_t)rgb_sum_dev & 15) || ((uintptr_t)out_dev & 1)) return fail(RT_ERR_INVALID, "rt_quantise_device: rgb_sum must be 16-byte and out 2-byte aligned");
+    if (spp == 0) return fail(RT_ERR_INVALID, "rt_quantise_device: samples_per_pixel is 0");
+    RT_HIP(launch_quantise(rgb_sum_dev, 3 * n_pixels, spp, out_dev, (hipStream_t)stream));
+    RT_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return RT_OK;
+  });
 }
 
 int rt_write_ppm_bytes(int fd, const uint8_t* rgb, uint32_t width, uint32_t height) {
-  if (!rgb && width && height) return fail(RT_ERR_INVALID, "rt_write_ppm_bytes: rgb is null");
-  if (!write_ppm_bytes(fd, rgb, width, height)) return fail(RT_ERR_IO, "rt_write_ppm_bytes: write failed");
-  return RT_OK;
+  return guarded("rt_write_ppm_bytes", [&]() -> int {
+    if (!rgb && width && height) return fail(RT_ERR_INVALID, "rt_write_ppm_bytes: rgb is null");
+    if (!write_ppm_bytes(fd, rgb, width, height)) return fail(RT_ERR_IO, "rt_write_ppm_bytes: write failed");
+    return RT_OK;
+  });
 }
 
-int rt_render_ppm(const rt_scene* sc, const rt_config* cfg, uint64_t seed, int fd, rt_render_stats* stats) {
-  if (!sc) return fail(RT_ERR_INVALID, "rt_render_ppm: scene is null");
-  CameraDev cam;
-  int rc = make_camera_dev(cfg, &cam, "rt_render_ppm");
-  if (rc) return rc;
-  if (cfg->samples_per_pixel == 0 || cfg->samples_per_pixel > 0xffffffffull) return fail(RT_ERR_INVALID, "rt_render_ppm: samples_per_pixel must be in 1 .. 2^32-1");
-  DeviceGuard g(sc->device);
-  RT_HIP(g.status);
-  const size_t n_px = (size_t)cam.width * cam.height;
-  DevBuf img, bytes;
-  RT_HIP(img.alloc(n_px * 24));
-  RT_HIP(bytes.alloc(n_px * 3 + 2));
-  RT_HIP(hipMemset(img.p, 0, n_px * 24));
-  rc = rt_render_device(sc, cfg, seed, 0, (uint32_t)cfg->samples_per_pixel, nullptr, img.as<double>(), nullptr, stats);
-  if (rc) return rc;
-  RT_HIP(launch_quantise(img.as<double>(), 3 * n_px, cfg->samples_per_pixel, bytes.as<uint8_t>(), nullptr));
-  std::vector<uint8_t> host(3 * n_px);
-  RT_HIP(hipMemcpy(host.data(), bytes.p, 3 * n_px, hipMemcpyDeviceToHost));
-  if (!write_ppm_bytes(fd, host.data(), cam.width, cam.height)) return fail(RT_ERR_IO, "rt_render_ppm: write failed");
-  return RT_OK;
+int rt_render_ppm(const rt_scene* sc_, const rt_config* cfg, uint64_t seed, int fd, rt_render_stats* stats) {
+  return guarded("rt_render_ppm", [&]() -> int {
+    rt_scene* sc = const_cast<rt_scene*>(sc_);
+    if (!sc) return fail(RT_ERR_INVALID, "rt_render_ppm: scene is null");
+    CameraDev cam;
+    int rc = make_camera_dev(cfg, &cam, "rt_render_ppm");
+    if (rc) return rc;
+    if (cfg->samples_per_pixel == 0 || cfg->samples_per_pixel > 0xffffffffull) return fail(RT_ERR_INVALID, "rt_render_ppm: samples_per_pixel must be in 1 .. 2^32-1");
+    if (cam.width > 0xffffu || cam.height > 0xffffu) return fail(RT_ERR_LIMIT, "rt_render_ppm: images larger than 65535 pixels on a side are not supported");
+    const uint32_t spp = (uint32_t)cfg->samples_per_pixel;
+    const size_t n_px = (size_t)cam.width * cam.height;
+    const rt_rect r{0, 0, cam.width, cam.height};
+    std::lock_guard<std::mutex> lock(sc->multi_mu);
+    // Tile rows dealt over the scene's devices: each renders, quantises and sends back its own rows, so the
+    // text does not depend on how many devices there are.
+    std::vector<rt_shard> shards;
+    rc = render_replicas(sc, cam, seed, RT_PARTITION_TILES, r, 0, spp, &shards, stats);
+    if (rc) return rc;
+    std::vector<uint8_t> host(3 * n_px);
+    rc = for_each_replica(sc->reps.size(), [&](size_t g) -> int {
+      Replica& rp = *sc->reps[g];
+      DeviceGuard dg(rp.device);
+      RT_HIP(dg.status);
+      size_t cap = rp.bytes_cap;
+      RT_HIP(grow_device((void**)&rp.bytes, &cap, 3 * n_px + 2));
+      rp.bytes_cap = cap;
+      RT_HIP(launch_quantise(rp.frame, 3 * n_px, spp, rp.bytes, rp.stream));
+      const rt_shard& sh = shards[g];
+      const uint32_t rows = shard_tile_rows(sh);
+      for (uint32_t k = 0; k < rows; ++k) {
+        const uint32_t y = (k * sh.row_stride + sh.row_first) * 8u, nrow = std::min(8u, cam.height - y);
+        const size_t off = (size_t)y * cam.width * 3;
+        RT_HIP(hipMemcpyAsync(host.data() + off, rp.bytes + off, (size_t)nrow * cam.width * 3, hipMemcpyDeviceToHost, rp.stream));
+      }
+      RT_HIP(hipStreamSynchronize(rp.stream));
+      return RT_OK;
+    });
+    if (rc) return rc;
+    if (!write_ppm_bytes(fd, host.data(), cam.width, cam.height)) return fail(RT_ERR_IO, "rt_render_ppm: write failed");
+    return RT_OK;
+  });
 }
 
 int rt_write_ppm(int fd, const double* rgb_sum, uint32_t width, uint32_t height, uint64_t spp) {
-  if (!rgb_sum && width && height) return fail(RT_ERR_INVALID, "rt_write_ppm: rgb_sum is null");
-  if (!write_ppm(fd, rgb_sum, width, height, spp)) return fail(RT_ERR_IO, "rt_write_ppm: write failed");
-  return RT_OK;
+  return guarded("rt_write_ppm", [&]() -> int {
+    if (!rgb_sum && width && height) return fail(RT_ERR_INVALID, "rt_write_ppm: rgb_sum is null");
+    if (!write_ppm(fd, rgb_sum, width, height, spp)) return fail(RT_ERR_IO, "rt_write_ppm: write failed");
+    return RT_OK;
+  });
 }
 
 int rt_scene_rtiow(uint64_t seed, rt_sphere* spheres, rt_material* materials) {

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -174,17 +175,22 @@ bool write_ppm_bytes(int fd, const uint8_t* rgb, uint32_t width, uint32_t height
   std::vector<size_t> lens(n_threads);
   for (size_t base = 0; base < n; base += batch * n_threads) {
     std::vector<std::thread> workers;
+    workers.reserve(n_threads);
     size_t used = 0;
     for (size_t t = 0; t < n_threads; ++t) {
       const size_t b = base + t * batch;
       if (b >= n) break;
       const size_t e = std::min(n, b + batch);
       ++used;
-      if (n_threads == 1) {
-        lens[t] = format_pixels(bt, rgb, b, e, bufs[t].data());
-      } else {
-        workers.emplace_back([&, t, b, e]() { lens[t] = format_pixels(bt, rgb, b, e, bufs[t].data()); });
+      bool threaded = false;
+      if (n_threads > 1) {
+        try {
+          workers.emplace_back([&, t, b, e]() { lens[t] = format_pixels(bt, rgb, b, e, bufs[t].data()); });
+          threaded = true;
+        } catch (const std::system_error&) {  // no thread to be had: format this batch here
+        }
       }
+      if (!threaded) lens[t] = format_pixels(bt, rgb, b, e, bufs[t].data());
     }
     for (auto& w : workers) w.join();
     for (size_t t = 0; t < used; ++t)

@@ -1,6 +1,8 @@
 // gfx950 kernels of the render hot path and their launchers.
 #include "rt_launch.h"
 
+#include <mutex>
+
 #include "rt_device.h"
 
 namespace rta {
@@ -261,8 +263,10 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
       px[1] += acc.y;
       px[2] += acc.z;
     } else {
-      const uint32_t tile_w = P.x1 - P.x0;
-      double* px = P.out + 3 * ((size_t)unit * tile_w * (P.y1 - P.y0) + (size_t)(j - P.y0) * tile_w + (i - P.x0));
+      // the partial sums hold the call's own tile rows only, packed: row (tile row / row_stride) * 8 + row within the tile
+      const uint32_t tile_w = P.x1 - P.x0, rel = j - P.y0;
+      const uint32_t row = P.row_stride == 1u ? rel : ((rel >> 3) / P.row_stride) * 8u + (rel & 7u);
+      double* px = P.out + 3 * ((size_t)unit * tile_w * P.local_rows + (size_t)row * tile_w + (i - P.x0));
       px[0] = acc.x;
       px[1] = acc.y;
       px[2] = acc.z;
@@ -322,9 +326,9 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           if (lane == 0) b = (uint32_t)min(atomicAdd(&P.counters[0], 1ull), (unsigned long long)P.n_batches);
           b = __builtin_amdgcn_readfirstlane(b);  // b == n_batches: nothing left (tile n_tiles starts at n_units)
           const uint32_t t = b / P.batches_per_tile, c0 = (b - t * P.batches_per_tile) * P.batch_chunks;
-          const uint32_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;
+          const uint32_t ty = t / P.tiles_x, tx = t - ty * P.tiles_x;  // ty: the call's own tile rows, row_stride apart in the rectangle
           wave_base = t * P.n_chunks * 64u;
-          wave_origin = (P.x0 + tx * 8u) | ((P.y0 + ty * 8u) << 16);
+          wave_origin = (P.x0 + tx * 8u) | ((P.y0 + (ty * P.row_stride + P.row_first) * 8u) << 16);
           const uint32_t first = min(wave_base + c0 * 64u, P.n_units);
           wave_end = min(wave_base + min(c0 + P.batch_chunks, P.n_chunks) * 64u, P.n_units);
           wave_next = min(first + (n_need - old_avail), wave_end);
@@ -491,24 +495,41 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
   }
 }
 
-// Adds the chunks' partial sums to the image in chunk order.
+// Adds the chunks' partial sums to the image in chunk order.  The partial sums hold `local_rows` packed rows of
+// `tile_w` pixels per chunk: packed row r is row (r / 8 * row_stride + row_first) * 8 + r % 8 of the rectangle.
 __global__ __launch_bounds__(256) void reduce_chunks_kernel(const double* __restrict__ partial, double* __restrict__ out, uint32_t n_chunks,
-                                                            uint32_t x0, uint32_t y0, uint32_t tile_w, uint32_t tile_h, uint32_t width) {
+                                                            uint32_t x0, uint32_t y0, uint32_t y1, uint32_t tile_w, uint32_t local_rows,
+                                                            uint32_t row_first, uint32_t row_stride, uint32_t width) {
   size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
-  size_t n = (size_t)tile_w * tile_h;
+  size_t n = (size_t)tile_w * local_rows;
   if (k >= n) return;
-  uint32_t y = (uint32_t)(k / tile_w), x = (uint32_t)(k - (size_t)y * tile_w);
-  double r = 0.0, g = 0.0, b = 0.0;
+  const uint32_t r = (uint32_t)(k / tile_w), x = (uint32_t)(k - (size_t)r * tile_w);
+  const uint32_t y = y0 + ((r >> 3) * row_stride + row_first) * 8u + (r & 7u);
+  if (y >= y1) return;  // the last tile row sticks out of the rectangle
+  double sr = 0.0, sg = 0.0, sb = 0.0;
   for (uint32_t c = 0; c < n_chunks; ++c) {
     const double* p = partial + 3 * ((size_t)c * n + k);
-    r += p[0];
-    g += p[1];
-    b += p[2];
+    sr += p[0];
+    sg += p[1];
+    sb += p[2];
   }
-  double* px = out + 3 * ((size_t)(y0 + y) * width + (x0 + x));
-  px[0] += r;
-  px[1] += g;
-  px[2] += b;
+  double* px = out + 3 * ((size_t)y * width + (x0 + x));
+  px[0] += sr;
+  px[1] += sg;
+  px[2] += sb;
+}
+
+// out[k] += sum of the n_src frames src[0..n_src)[k], added in that order, for k in [begin, end): the frames of a
+// sample split on several GPUs brought together (src may be memory of peer devices).
+struct FrameList {
+  const double* src[16];
+};
+__global__ __launch_bounds__(256) void add_frames_kernel(double* __restrict__ out, FrameList frames, uint32_t n_src, size_t begin, size_t end) {
+  for (size_t k = begin + (size_t)blockIdx.x * 256 + threadIdx.x; k < end; k += (size_t)gridDim.x * 256) {
+    double v = out[k];
+    for (uint32_t f = 0; f < n_src; ++f) v += frames.src[f][k];
+    out[k] = v;
+  }
 }
 
 // ---------------------------------------------------------------- quantise ----
@@ -611,12 +632,23 @@ hipError_t launch_render(const RenderParams& P, int blocks, bool profile, hipStr
   return hipGetLastError();
 }
 
-hipError_t launch_reduce_chunks(const double* partial, double* out, uint32_t n_chunks, uint32_t x0, uint32_t y0, uint32_t tile_w,
-                                uint32_t tile_h, uint32_t width, hipStream_t stream) {
-  size_t n = (size_t)tile_w * tile_h;
+hipError_t launch_reduce_chunks(const double* partial, double* out, uint32_t n_chunks, uint32_t x0, uint32_t y0, uint32_t y1, uint32_t tile_w,
+                                uint32_t local_rows, uint32_t row_first, uint32_t row_stride, uint32_t width, hipStream_t stream) {
+  size_t n = (size_t)tile_w * local_rows;
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, out, n_chunks, x0, y0, tile_w,
-                     tile_h, width);
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, out, n_chunks, x0, y0, y1, tile_w,
+                     local_rows, row_first, row_stride, width);
+  return hipGetLastError();
+}
+
+hipError_t launch_add_frames(double* out, const double* const* src, uint32_t n_src, size_t begin, size_t end, hipStream_t stream) {
+  if (end <= begin || n_src == 0) return hipSuccess;
+  if (n_src > kMaxAddFrames) return hipErrorInvalidValue;
+  FrameList fl{};
+  for (uint32_t f = 0; f < n_src; ++f) fl.src[f] = src[f];
+  size_t blocks = (end - begin + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(add_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, out, fl, n_src, begin, end);
   return hipGetLastError();
 }
 

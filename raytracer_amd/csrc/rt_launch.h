@@ -46,6 +46,9 @@ struct RenderParams {
   CameraDev cam;
   uint32_t x0, y0, x1, y1;  // tile
   uint32_t tiles_x, n_tiles;
+  // The call renders the tile rows (8 pixel rows each) of the rectangle whose index is row_first modulo row_stride
+  // (all of them with 0 and 1: the single-GPU case); local_rows = 8 x the number of those tile rows.
+  uint32_t row_first, row_stride, local_rows;
   uint32_t n_chunks, chunk_spp;
   uint32_t spp_begin, spp_end;
   uint32_t seed_lo, seed_hi;
@@ -84,8 +87,11 @@ hipError_t launch_primary_rays(const CameraDev& cam, uint64_t seed, const uint32
                                hipStream_t stream);
 // profile: run the variant that also fills the profiling counters.
 hipError_t launch_render(const RenderParams& P, int blocks, bool profile, hipStream_t stream);
-hipError_t launch_reduce_chunks(const double* partial, double* out, uint32_t n_chunks, uint32_t x0, uint32_t y0, uint32_t tile_w,
-                                uint32_t tile_h, uint32_t width, hipStream_t stream);
+hipError_t launch_reduce_chunks(const double* partial, double* out, uint32_t n_chunks, uint32_t x0, uint32_t y0, uint32_t y1, uint32_t tile_w,
+                                uint32_t local_rows, uint32_t row_first, uint32_t row_stride, uint32_t width, hipStream_t stream);
+// out[k] += src[0][k] + ... + src[n_src-1][k] (in that order) for k in [begin, end); at most kMaxAddFrames sources.
+constexpr uint32_t kMaxAddFrames = 16;
+hipError_t launch_add_frames(double* out, const double* const* src, uint32_t n_src, size_t begin, size_t end, hipStream_t stream);
 // out (bytes, 2-byte aligned) = write_colour of each of the n_components sums.
 hipError_t launch_quantise(const double* rgb_sum, size_t n_components, uint64_t spp, uint8_t* out, hipStream_t stream);
 

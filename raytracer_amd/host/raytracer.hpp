@@ -153,7 +153,8 @@ class BVH {
       }
       spheres.push_back({{s->center.x, s->center.y, s->center.z}, s->radius, it->second, 0});
     }
-    check(rt_scene_create(spheres.data(), spheres.size(), materials.data(), materials.size(), &scene_));
+    // one copy of the tree on every GPU of the node (null device list); Camera::render shares a frame out over them
+    check(rt_scene_create_multi(spheres.data(), spheres.size(), materials.data(), materials.size(), RT_BUILD_HOST_SAH, nullptr, 0, &scene_));
   }
   ~BVH() {
     if (scene_) rt_scene_destroy(scene_);

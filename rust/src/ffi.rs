@@ -7,6 +7,8 @@ pub const RT_METAL: u32 = 1;
 pub const RT_DIELECTRIC: u32 = 2;
 pub const RT_BUILD_HOST_SAH: u32 = 0;
 pub const RT_BUILD_DEVICE_LBVH: u32 = 1;
+pub const RT_PARTITION_TILES: u32 = 0;
+pub const RT_PARTITION_SAMPLES: u32 = 1;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -84,7 +86,28 @@ extern "C" {
         builder: u32,
         out: *mut *mut rt_scene,
     ) -> c_int;
+    pub fn rt_scene_create_multi(
+        spheres: *const rt_sphere,
+        n_spheres: usize,
+        materials: *const rt_material,
+        n_materials: usize,
+        builder: u32,
+        devices: *const i32,
+        n_devices: usize,
+        out: *mut *mut rt_scene,
+    ) -> c_int;
     pub fn rt_scene_destroy(scene: *mut rt_scene) -> c_int;
+    pub fn rt_render_multi(
+        scene: *const rt_scene,
+        cfg: *const rt_config,
+        seed: u64,
+        spp_begin: u32,
+        spp_end: u32,
+        tile: *const rt_rect,
+        partition: u32,
+        rgb_sum: *mut f64,
+        stats: *mut rt_render_stats,
+    ) -> c_int;
     pub fn rt_render(
         scene: *const rt_scene,
         cfg: *const rt_config,

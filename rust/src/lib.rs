@@ -78,8 +78,20 @@ impl Scene {
             };
             flat.push(ffi::rt_sphere { center: s.center.to_array(), radius: s.radius, material: index as u32, reserved: 0 });
         }
+        // A copy of the scene on every GPU of the node (null device list): `render` and `render_ppm` use them all.
         let mut handle = ptr::null_mut();
-        check(unsafe { ffi::rt_scene_create(flat.as_ptr(), flat.len(), materials.as_ptr(), materials.len(), &mut handle) })?;
+        check(unsafe {
+            ffi::rt_scene_create_multi(
+                flat.as_ptr(),
+                flat.len(),
+                materials.as_ptr(),
+                materials.len(),
+                ffi::RT_BUILD_HOST_SAH,
+                ptr::null(),
+                0,
+                &mut handle,
+            )
+        })?;
         Ok(Self(handle))
     }
 
@@ -88,7 +100,17 @@ impl Scene {
         let mut sums = vec![0.0f64; cfg.image_width as usize * image_height as usize * 3];
         let mut stats = ffi::rt_render_stats::default();
         check(unsafe {
-            ffi::rt_render(self.0, cfg, seed, 0, cfg.samples_per_pixel as u32, ptr::null(), sums.as_mut_ptr(), &mut stats)
+            ffi::rt_render_multi(
+                self.0,
+                cfg,
+                seed,
+                0,
+                cfg.samples_per_pixel as u32,
+                ptr::null(),
+                ffi::RT_PARTITION_TILES,
+                sums.as_mut_ptr(),
+                &mut stats,
+            )
         })?;
         Ok((sums, stats))
     }

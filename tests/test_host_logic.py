@@ -183,3 +183,133 @@ def test_cxx_driver_fails_loudly_without_a_gpu():
         pass
     p = subprocess.run([exe, "--width", "32", "--spp", "1"], capture_output=True, timeout=60)
     assert p.returncode == 1 and p.stdout == b"" and b"hip" in p.stderr.lower()
+
+
+def test_debug_knobs_refuse_values_that_would_hang_a_wave():
+    import ctypes as C
+
+    L = rt._lib.lib()
+    for name in (b"inner_min", b"leaf_min"):
+        for bad in (0.0, -1.0, 65.0, 2.5, float("nan"), float("inf")):
+            assert L.rt_debug_set(name, C.c_double(bad)) == 1, (name, bad)
+            assert b"1 .. 64" in L.rt_last_error()
+        assert L.rt_debug_set(name, C.c_double(10.0)) == 0
+    for bad in (-1.0, 65.0, float("nan")):
+        assert L.rt_debug_set(b"both_min", C.c_double(bad)) == 1
+    assert L.rt_debug_set(b"both_min", C.c_double(0.0)) == 0 and L.rt_debug_set(b"both_min", C.c_double(8.0)) == 0
+    assert L.rt_debug_set(b"batches_per_wave", C.c_double(0.0)) == 1 and L.rt_debug_set(b"batches_per_wave", C.c_double(32.0)) == 0
+    assert L.rt_debug_set(b"no_such_knob", C.c_double(1.0)) == 1
+
+
+def test_partition_covers_the_request_exactly_once():
+    # what rt_render_multi hands to each device (host code only)
+    cam = rt.config_rtiow(image_width=131, samples_per_pixel=50).camera()
+    h = cam.image_height
+    for tile in (None, (3, 5, 120, 70), (0, 0, 131, 7), (10, 10, 10, 40)):
+        x0, y0, x1, y1 = tile if tile else (0, 0, 131, h)
+        for n in (1, 2, 3, 8, 16):
+            shards = cam.partition(n, rt.PARTITION_TILES, spp_begin=4, spp_end=50, tile=tile)
+            owner = np.full(max(0, y1 - y0), -1)
+            for g, s in enumerate(shards):
+                assert (int(s["x0"]), int(s["y0"]), int(s["x1"]), int(s["y1"])) == (x0, y0, x1, y1)
+                assert (int(s["spp_begin"]), int(s["spp_end"])) == (4, 50) and int(s["row_stride"]) == n and int(s["row_first"]) == g
+                rows = [r for r in range(y1 - y0) if (r // 8) % n == g]
+                assert (owner[rows] == -1).all()
+                owner[rows] = g
+            assert (owner >= 0).all()
+            shards = cam.partition(n, rt.PARTITION_SAMPLES, spp_begin=4, spp_end=50, tile=tile)
+            at, sizes = 4, []
+            for s in shards:
+                assert int(s["row_first"]) == 0 and int(s["row_stride"]) == 1 and int(s["spp_begin"]) == at
+                sizes.append(int(s["spp_end"]) - at)
+                at = int(s["spp_end"])
+            assert at == 50 and max(sizes) - min(sizes) <= 1
+    with pytest.raises(rt.RtError):
+        cam.partition(0)
+    with pytest.raises(rt.RtError):
+        cam.partition(2, tile=(0, 0, 200, 10))
+    with pytest.raises(rt.RtError):
+        cam.partition(2, partition=2)
+
+
+def _c_declarations(text):
+    """{name: [parameter types]} for the functions and {name: [(type, field)]} for the structs of a C header."""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    structs = {}
+    for body, name in re.findall(r"typedef struct \w+ \{(.*?)\} (\w+);", text, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            ctype, names = decl.rsplit(" ", 1)[0], decl.split(" ", 1)[1] if decl.count(" ") == 1 else None
+            m = re.match(r"(\w+)\s+(.*)", decl)
+            ctype, names = m.group(1), m.group(2)
+            for nm in names.split(","):
+                nm = nm.strip()
+                dim = re.search(r"\[(\d+)\]", nm)
+                fields.append((ctype + ("[%s]" % dim.group(1) if dim else ""), re.sub(r"\[.*", "", nm)))
+        structs[name] = fields
+    funcs = {}
+    for ret, name, params in re.findall(r"^(int|void|const char\*)\s+(rt_\w+)\(([^)]*)\);", text, flags=re.M | re.S):
+        plist = []
+        for p in params.split(","):
+            p = " ".join(p.split())
+            if p in ("void", ""):
+                continue
+            ptype = re.sub(r"\s*\w+$", "", p)  # drop the parameter name
+            plist.append(ptype.replace(" *", "*"))
+        funcs[name] = plist
+    return structs, funcs
+
+
+_RUST_TYPES = {
+    "u8": "uint8_t", "u32": "uint32_t", "u64": "uint64_t", "i32": "int32_t", "f32": "float", "f64": "double", "usize": "size_t",
+    "c_int": "int", "c_char": "char", "c_void": "void",
+}
+
+
+def _rust_type_to_c(t):
+    t = t.strip()
+    m = re.match(r"\*(const|mut) (.*)", t)
+    if m:
+        inner = _rust_type_to_c(m.group(2))
+        return ("const " if m.group(1) == "const" else "") + inner + "*"
+    m = re.match(r"\[(\w+); (\d+)\]", t)
+    if m:
+        return "%s[%s]" % (_RUST_TYPES[m.group(1)], m.group(2))
+    return _RUST_TYPES.get(t, t)
+
+
+def test_rust_ffi_declarations_match_the_header():
+    # No Rust toolchain exists here, so the crate under rust/ cannot be compiled; this keeps its raw declarations
+    # honest: every extern function and #[repr(C)] struct in rust/src/ffi.rs must agree with include/rt.h in name,
+    # argument count, argument types and field order.
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs, funcs = _c_declarations(open(os.path.join(root, "include", "rt.h")).read())
+    src = open(os.path.join(root, "rust", "src", "ffi.rs")).read()
+    src = re.sub(r"//.*", "", src)
+    n_structs = 0
+    for name, body in re.findall(r"#\[repr\(C\)\]\s*(?:#\[derive\([^)]*\)\]\s*)?pub struct (\w+) \{(.*?)\n\}", src, flags=re.S):
+        if name == "rt_scene":
+            continue  # opaque
+        fields = [(f.strip().split(":")[0].replace("pub ", "").strip(), _rust_type_to_c(f.split(":")[1])) for f in body.split(",") if ":" in f]
+        want = structs[name]
+        assert len(fields) == len(want), name
+        for (rname, rtype), (ctype, cname) in zip(fields, want):
+            assert rtype == ctype, (name, rname, rtype, ctype)
+            assert rname == cname or (rname, cname) == ("kind", "type"), (name, rname, cname)  # `type` is a Rust keyword
+        n_structs += 1
+    assert n_structs >= 5
+    block = re.search(r'extern "C" \{(.*)\n\}', src, flags=re.S).group(1)
+    n_funcs = 0
+    for name, params, ret in re.findall(r"pub fn (rt_\w+)\((.*?)\)\s*->\s*([^;]+);", block, flags=re.S):
+        assert name in funcs, name + " is not declared in include/rt.h"
+        rparams = [_rust_type_to_c(p.split(":", 1)[1]) for p in params.split(",") if ":" in p]
+        assert rparams == funcs[name], (name, rparams, funcs[name])
+        n_funcs += 1
+    assert n_funcs >= 10
+    # the C constants the crate repeats
+    header = open(os.path.join(root, "include", "rt.h")).read()
+    for cname, value in re.findall(r"pub const (RT_\w+): u32 = (\d+);", src):
+        assert re.search(r"\b%s = %s\b" % (cname, value), header), cname
