@@ -255,6 +255,19 @@ int rt_partition(const rt_config* cfg, uint32_t spp_begin, uint32_t spp_end, con
 int rt_render_multi(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile,
                     uint32_t partition, double* rgb_sum, rt_render_stats* stats);
 
+/* rt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The launch's counters and per-chunk
+ * sums live in a 32 MiB static device array that every GPU the library runs on holds until the process ends; the
+ * call makes no hipMalloc, hipFree, event or other allocating call.  The request is cut into chunks exactly as
+ * rt_render_device cuts it, so the frame is bit for bit the same; a request whose per-chunk sums exceed the array
+ * (n_chunks x pixels x 24 bytes > 32 MiB - 256; frames too large for that still fit when their sample range is
+ * short enough to be one chunk) or whose tree needs traversal stacks in global memory is refused with
+ * RT_ERR_LIMIT.  The kernels are enqueued on `stream`; with stats == NULL the call returns without waiting for
+ * them, otherwise it waits and fills stats (kernel_ms stays 0: no events).  All calls on one GPU share that
+ * GPU's array: calls that overlap in time on one GPU race. */
+int rt_render_device_noalloc(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
+                             const rt_rect* tile, double* rgb_sum_dev, void* stream, rt_render_stats* stats);
+
 /* Tuning knobs and test hooks; not part of the stable interface.  Known names:
  * "inner_min" (lanes of 64 that must want the inner-node block for a wave to run
  * it without counting the other blocks), "leaf_min" (lanes waiting at leaves that make the leaf block run between

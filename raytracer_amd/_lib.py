@@ -91,6 +91,7 @@ EXPORTS = [
     "rt_render",
     "rt_render_device",
     "rt_render_shard_device",
+    "rt_render_device_noalloc",
     "rt_partition",
     "rt_render_multi",
     "rt_debug_set",

@@ -307,6 +307,19 @@ class Camera:
                                                 C.c_void_p(stream or 0), ptr(stats)))
         return {k: stats[k][0].item() for k in RENDER_STATS_DTYPE.names}
 
+    def render_device_noalloc(self, bvh, rgb_sum_ptr, seed=0, spp_begin=0, spp_end=None, tile=None, stream=None, want_stats=True):
+        """render_device through the entry point that allocates nothing (static device workspace)."""
+        if spp_end is None:
+            spp_end = self.config.get("samples_per_pixel")
+        rect = None
+        if tile is not None:
+            rect = np.zeros(1, dtype=RECT_DTYPE)
+            rect["x0"], rect["y0"], rect["x1"], rect["y1"] = tile
+        stats = np.zeros(1, dtype=RENDER_STATS_DTYPE) if want_stats else None
+        check(_lib.lib().rt_render_device_noalloc(bvh._h, ptr(self.config.record()), C.c_uint64(seed), C.c_uint32(spp_begin),
+                                                  C.c_uint32(spp_end), ptr(rect), C.c_void_p(rgb_sum_ptr), C.c_void_p(stream or 0), ptr(stats)))
+        return {k: stats[k][0].item() for k in RENDER_STATS_DTYPE.names} if want_stats else None
+
     def partition(self, n_devices, partition=PARTITION_TILES, spp_begin=0, spp_end=None, tile=None):
         """The shares `render_multi` gives to n_devices devices: an array of SHARD_DTYPE records."""
         if spp_end is None:

@@ -794,6 +794,18 @@ int render_replicas(rt_scene* sc, const CameraDev& cam, uint64_t seed, uint32_t 
   return RT_OK;
 }
 
+// The library's static device array (rt_kernels.hip) as a workspace: counters in its first 256 bytes, per-chunk sums after them.
+int static_workspace(int device, Workspace* ws) {
+  void* base = nullptr;
+  size_t bytes = 0;
+  RT_HIP(static_scratch(device, &base, &bytes));
+  ws->fixed = true;
+  ws->counters = static_cast<unsigned long long*>(base);
+  ws->partial = reinterpret_cast<double*>(static_cast<char*>(base) + 256);
+  ws->partial_cap = bytes - 256;
+  return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1053,6 +1065,51 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
   if (rc) return rc;
   rt_shard sh{tile ? *tile : rt_rect{0, 0, cfg->image_width, c.image_height}, 0, 1, spp_begin, spp_end};
   return rt_render_shard_device(sc, cfg, seed, &sh, rgb_sum_dev, stream, stats);
+}
+
+int rt_render_device_noalloc(const rt_scene* sc, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
+                             const rt_rect* tile, double* rgb_sum_dev, void* stream, rt_render_stats* stats) {
+  return guarded("rt_render_device_noalloc", [&]() -> int {
+    if (!sc) return fail(RT_ERR_INVALID, "rt_render_device_noalloc: scene is null");
+    if (!rgb_sum_dev) return fail(RT_ERR_INVALID, "rt_render_device_noalloc: rgb_sum is null");
+    CameraDev cam;
+    int rc = make_camera_dev(cfg, &cam, "rt_render_device_noalloc");
+    if (rc) return rc;
+    const rt_shard sh{tile ? *tile : rt_rect{0, 0, cam.width, cam.height}, 0, 1, spp_begin, spp_end};
+    rc = check_shard(cam, sh, "rt_render_device_noalloc");
+    if (rc) return rc;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    Replica& rp = *sc->reps[0];
+    DeviceGuard g(rp.device);
+    RT_HIP(g.status);
+    Workspace ws;
+    rc = static_workspace(rp.device, &ws);
+    if (rc) return rc;
+    // Cut into chunks exactly as rt_render_device does, so that the sums come out the same; a request whose
+    // per-chunk sums or traversal stacks do not fit in the static array is refused, not rendered differently.
+    Launch L;
+    rc = plan_render(rp, cam, seed, sh, kWorkspaceLimit, &L);
+    if (rc) return rc;
+    if (L.nothing) {
+      if (stats && cam.max_depth == 0) stats->samples = L.samples;
+      return RT_OK;
+    }
+    if (L.gstack_bytes)
+      return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: this scene's tree is too deep for traversal stacks in LDS and needs " +
+                                    std::to_string(L.gstack_bytes) + " bytes of stacks in global memory; use rt_render_device");
+    if (L.partial_bytes > ws.partial_cap)
+      return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: the request needs " + std::to_string(L.partial_bytes) +
+                                    " bytes of per-chunk sums, the static workspace holds " + std::to_string(ws.partial_cap) +
+                                    "; render a smaller tile or sample range per call, or use rt_render_device");
+    uint32_t launches = 0;
+    rc = enqueue_render(L, ws, rgb_sum_dev, static_cast<hipStream_t>(stream), false, &launches);
+    if (rc) return rc;
+    if (stats) {  // the counters can only be read once the kernels have finished
+      RT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+      rc = read_stats(L, ws, launches, false, stats);
+    }
+    return rc;
+  });
 }
 
 int rt_render(const rt_scene* sc, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile,

@@ -553,6 +553,40 @@ __global__ __launch_bounds__(256) void quantise_kernel(const double* __restrict_
   if ((n_components & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n_components - 1] = (uint8_t)q(rgb_sum[n_components - 1]);
 }
 
+// --------------------------------------------------------- static workspace ----
+// Device memory for render calls that must not allocate (rt_render_device_noalloc): the launch's counters and its
+// per-chunk sums.  One copy per GPU, at its own address, held from the time the code object is loaded until the
+// process ends.  `scratch` names the array in device code; host code may only use the address that
+// hipGetSymbolAddress returns for it on each device.
+constexpr size_t kScratchBytes = 32u << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxScratchDevices = 64;
+hipError_t static_scratch(int device, void** ptr, size_t* bytes) {
+  static std::mutex mu;
+  static void* address[kMaxScratchDevices] = {};
+  if (device < 0 || device >= kMaxScratchDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!address[device]) {  // first use on this device: look the array's address up there
+    int current = -1;
+    hipError_t e = hipGetDevice(&current);
+    if (e != hipSuccess) return e;
+    if (current != device) {
+      e = hipSetDevice(device);
+      if (e != hipSuccess) return e;
+    }
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (current != device) (void)hipSetDevice(current);
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    address[device] = p;
+  }
+  *ptr = address[device];
+  *bytes = kScratchBytes;
+  return hipSuccess;
+}
+
 // --------------------------------------------------------------- launchers ----
 size_t lds_node_bytes() { return kLdsNodeQuads * 16; }
 size_t lds_fixed_bytes() { return CAM_DOUBLES * 8; }

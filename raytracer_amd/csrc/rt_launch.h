@@ -92,6 +92,8 @@ hipError_t launch_reduce_chunks(const double* partial, double* out, uint32_t n_c
 // out[k] += src[0][k] + ... + src[n_src-1][k] (in that order) for k in [begin, end); at most kMaxAddFrames sources.
 constexpr uint32_t kMaxAddFrames = 16;
 hipError_t launch_add_frames(double* out, const double* const* src, uint32_t n_src, size_t begin, size_t end, hipStream_t stream);
+// The library's static device array on `device` (one copy per GPU): its address there and its size.  Nothing is allocated.
+hipError_t static_scratch(int device, void** ptr, size_t* bytes);
 // out (bytes, 2-byte aligned) = write_colour of each of the n_components sums.
 hipError_t launch_quantise(const double* rgb_sum, size_t n_components, uint64_t spp, uint8_t* out, hipStream_t stream);
 
