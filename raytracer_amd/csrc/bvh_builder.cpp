@@ -436,4 +436,111 @@ FlatBvh flatten_bvh(const HostBvh& bvh, const rt_sphere* spheres, size_t n) {
   return f;
 }
 
+WideBvh collapse_wide(const DevNode* nodes, size_t n_nodes) {
+  WideBvh w;
+  if (n_nodes == 0) return w;
+  struct Child {
+    float lo[3], hi[3];
+    uint32_t ref;
+  };
+  auto children_of = [&](uint32_t b, Child out[2]) {
+    const DevNode& d = nodes[b];
+    for (int c = 0; c < 2; ++c) {
+      out[c].lo[0] = d.x[2 * c];
+      out[c].hi[0] = d.x[2 * c + 1];
+      out[c].lo[1] = d.y[2 * c];
+      out[c].hi[1] = d.y[2 * c + 1];
+      out[c].lo[2] = d.z[2 * c];
+      out[c].hi[2] = d.z[2 * c + 1];
+      out[c].ref = c == 0 ? d.ref0 : d.ref1;
+    }
+  };
+  auto area = [](const Child& c) {
+    const double dx = (double)c.hi[0] - c.lo[0], dy = (double)c.hi[1] - c.lo[1], dz = (double)c.hi[2] - c.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  };
+  // breadth-first over the wide nodes; each is rooted at a two-wide inner node
+  std::vector<uint32_t> root_of{0};
+  std::vector<uint32_t> level{1};
+  w.nodes.reserve(n_nodes / 2 + 1);
+  double bound = 0.0;
+  for (size_t head = 0; head < root_of.size(); ++head) {
+    Child ch[4];
+    int n = 2;
+    children_of(root_of[head], ch);
+    while (n < 4) {
+      int pick = -1;
+      double best = -1.0;
+      for (int k = 0; k < n; ++k)
+        if (!(ch[k].ref & kRefLeaf) && area(ch[k]) > best) {
+          best = area(ch[k]);
+          pick = k;
+        }
+      if (pick < 0) break;
+      Child two[2];
+      children_of(ch[pick].ref, two);
+      ch[pick] = two[0];
+      ch[n++] = two[1];
+    }
+    WideNode node{};
+    for (int a = 0; a < 3; ++a) {
+      float lo = ch[0].lo[a], hi = ch[0].hi[a];
+      for (int k = 1; k < n; ++k) {
+        lo = std::fmin(lo, ch[k].lo[a]);
+        hi = std::fmax(hi, ch[k].hi[a]);
+      }
+      // the smallest power of two s with 255 s >= extent (all in double: exact for f32 inputs); one step up
+      // if rounding the corner down to f32 makes the extent from it exceed that
+      const double extent = (double)hi - (double)lo;
+      int e = -100;
+      if (extent > 0.0) {
+        int ex;
+        const double m = std::frexp(extent / 255.0, &ex);  // extent / 255 = m 2^ex, m in [0.5, 1)
+        e = m == 0.5 ? ex - 1 : ex;
+        if (e < -100) e = -100;
+      }
+      double s, base;
+      float corner;
+      for (;; ++e) {
+        s = std::ldexp(1.0, e);
+        corner = round_down((double)lo - 1024.0 * s);
+        base = (double)corner + 1024.0 * s;  // plane of q = 0; at or below lo
+        if (std::ceil(((double)hi - base) / s) <= 255.0) break;
+      }
+      (a == 0 ? node.origin_x : a == 1 ? node.origin_y : node.origin_z) = corner;
+      (a == 0 ? node.step_x : a == 1 ? node.step_y : node.step_z) = (float)s;
+      bound = std::fmax(bound, std::fabs((double)corner));
+      uint32_t ql = 0, qh = 0;
+      for (int k = 0; k < 4; ++k) {
+        uint32_t l = 255, h = 0;  // absent child: inverted
+        if (k < n) {
+          l = (uint32_t)std::min(255.0, std::floor(((double)ch[k].lo[a] - base) / s));
+          h = (uint32_t)std::min(255.0, std::ceil(((double)ch[k].hi[a] - base) / s));
+          bound = std::fmax(bound, std::fmax(std::fabs(base + l * s), std::fabs(base + h * s)));
+        }
+        ql |= l << (8 * k);
+        qh |= h << (8 * k);
+      }
+      node.qlo[a] = ql;
+      node.qhi[a] = qh;
+    }
+    for (int k = 0; k < 4; ++k) {
+      if (k >= n) {
+        node.ref[k] = kRefNone;
+      } else if (ch[k].ref & kRefLeaf) {
+        node.ref[k] = ch[k].ref;
+      } else {
+        node.ref[k] = (uint32_t)root_of.size();
+        root_of.push_back(ch[k].ref);
+        level.push_back(level[head] + 1);
+      }
+    }
+    w.depth = std::max(w.depth, level[head]);
+    w.nodes.push_back(node);
+  }
+  w.stack_entries = 3 * w.depth + 1;  // at most three children set aside per level
+  w.bound = round_up(bound);
+  return w;
+}
+
 }  // namespace rta

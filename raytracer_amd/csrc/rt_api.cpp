@@ -15,6 +15,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "bvh_builder.h"
@@ -108,6 +109,8 @@ std::atomic<bool> g_force_global_stack{false};
 // Test hook: rt_render_multi brings the frames of a sample split together through a copy on the first device even
 // where the devices can read each other's memory.
 std::atomic<bool> g_force_staged_sum{false};
+// Entries of a lane's traversal stack that the four-wide walk keeps in LDS (deeper ones go to global memory).
+std::atomic<uint32_t> g_wide_lds_stack{8};
 
 // Partial sums of an allocating render call never exceed this; the sample range is cut into fewer chunks instead.
 constexpr uint64_t kWorkspaceLimit = 4ull << 30;
@@ -179,7 +182,8 @@ struct rt_scene {
   std::vector<std::vector<uint8_t>> peer;      // peer[a][b]: device of replica a can read the memory of replica b's
   HostBvh host;
   size_t n_spheres = 0, n_materials = 0;
-  std::vector<uint8_t> material_type;
+  std::vector<uint8_t> material_type;   // by index into the device's material table
+  std::vector<uint32_t> table_index;    // caller's material index -> index into the device's material table
   rt_scene_info info{};
   std::mutex multi_mu;  // one multi-device call per scene at a time (they share the replicas' frames)
 };
@@ -224,9 +228,9 @@ int make_camera_dev(const rt_config* cfg, CameraDev* cam, const char* who) {
 
 // ------------------------------------------------------------ scene set-up ----
 // Uploads one copy of the scene to the current device (or builds the tree there) and plans its LDS image.
-int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, const std::vector<double>& mats,
-                 const std::vector<uint8_t>& material_type, bool on_device_wanted, const FlatBvh* flat_in, size_t max_depth, bool* on_device_out,
-                 uint32_t* depth_out, size_t* n_dev_nodes_out) {
+int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, size_t n_used, const std::vector<double>& mats,
+                 const std::vector<uint8_t>& material_type, bool on_device_wanted, const FlatBvh* flat_in, size_t max_depth, WideBvh* wide_cache,
+                 bool* on_device_out, uint32_t* depth_out, size_t* n_dev_nodes_out) {
   RT_HIP(hipGetDevice(&rp.device));
   hipDeviceProp_t prop;
   RT_HIP(hipGetDeviceProperties(&prop, rp.device));
@@ -264,7 +268,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, con
   const size_t stack_bytes = stack_in_lds ? (size_t)depth * kWorkgroup * 4 : 0;
   size_t room = kLdsPerCu - stack_bytes - reserve;
   const size_t node_bytes = n_dev_nodes * sizeof(DevNode), sph_bytes = n * sizeof(DevSphere);
-  const size_t aux_bytes = n * sizeof(DevSphereAux), mat_bytes = nm * 32;
+  const size_t aux_bytes = n * sizeof(DevSphereAux), mat_bytes = nm * 32, used_mat_bytes = n_used * 32;  // nm: records in the table
   uint32_t n_nodes_lds = (uint32_t)std::min(n_dev_nodes, room / lds_node_bytes());
   room -= n_nodes_lds * lds_node_bytes();
   uint32_t n_sph_lds = 0, n_aux_lds = 0, n_mat_lds = 0;
@@ -275,16 +279,46 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, con
       if (aux_bytes <= room) {
         n_aux_lds = (uint32_t)n;
         room -= aux_bytes;
-        if (mat_bytes <= room) n_mat_lds = (uint32_t)nm;
+        if (used_mat_bytes <= room) n_mat_lds = (uint32_t)n_used;
       }
     }
   }
 
-  if (!on_device) {
+  // A scene that fits in LDS as a whole is walked through its two-wide tree; any other through the four-wide
+  // tree with quantised boxes (half the bytes per ray), collapsed here from the two-wide nodes.
+  const bool fits = n_nodes_lds == n_dev_nodes && n_sph_lds == n && n_aux_lds == n && n_mat_lds == n_used;
+  const bool wide = !fits && n_dev_nodes > 0;
+  uint32_t lds_stack = 0;
+  size_t n_final_nodes = n_dev_nodes;
+  if (wide) {
+    if (wide_cache->nodes.empty()) {
+      if (on_device) {
+        std::vector<DevNode> host_nodes(n_dev_nodes);
+        RT_HIP(hipMemcpy(host_nodes.data(), rp.d_nodes, node_bytes, hipMemcpyDeviceToHost));
+        *wide_cache = collapse_wide(host_nodes.data(), n_dev_nodes);
+      } else {
+        *wide_cache = collapse_wide(flat.nodes.data(), n_dev_nodes);
+      }
+    }
+    if (on_device) {
+      (void)hipFree(rp.d_nodes);
+      rp.d_nodes = nullptr;
+    }
+    const WideBvh& wb = *wide_cache;
+    n_final_nodes = wb.nodes.size();
+    lds_stack = g_force_global_stack.load() ? 0u : std::min<uint32_t>(wb.stack_entries, g_wide_lds_stack.load());
+    const size_t wide_room = kLdsPerCu - reserve - (size_t)lds_stack * kWorkgroup * 4;
+    n_nodes_lds = (uint32_t)std::min(n_final_nodes, wide_room / lds_wide_node_bytes());
+    n_sph_lds = n_aux_lds = n_mat_lds = 0;
+    RT_HIP(hipMalloc(&rp.d_nodes, n_final_nodes * sizeof(WideNode)));
+    RT_HIP(hipMemcpy(rp.d_nodes, wb.nodes.data(), n_final_nodes * sizeof(WideNode), hipMemcpyHostToDevice));
+  } else if (!on_device) {
     RT_HIP(hipMalloc(&rp.d_nodes, node_bytes ? node_bytes : 64));
+    if (node_bytes) RT_HIP(hipMemcpy(rp.d_nodes, flat.nodes.data(), node_bytes, hipMemcpyHostToDevice));
+  }
+  if (!on_device) {
     RT_HIP(hipMalloc(&rp.d_spheres, sph_bytes ? sph_bytes : 32));
     RT_HIP(hipMalloc(&rp.d_aux, aux_bytes ? aux_bytes : 16));
-    if (node_bytes) RT_HIP(hipMemcpy(rp.d_nodes, flat.nodes.data(), node_bytes, hipMemcpyHostToDevice));
     if (sph_bytes) RT_HIP(hipMemcpy(rp.d_spheres, flat.spheres.data(), sph_bytes, hipMemcpyHostToDevice));
     if (aux_bytes) RT_HIP(hipMemcpy(rp.d_aux, flat.aux.data(), aux_bytes, hipMemcpyHostToDevice));
   }
@@ -296,17 +330,19 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, con
   dev.spheres = static_cast<const double2*>(rp.d_spheres);
   dev.aux = static_cast<const double2*>(rp.d_aux);
   dev.materials = static_cast<const double2*>(rp.d_materials);
-  dev.n_nodes = (uint32_t)n_dev_nodes;
+  dev.n_nodes = (uint32_t)n_final_nodes;
   dev.n_spheres = (uint32_t)n;
-  dev.n_materials = (uint32_t)nm;
+  dev.n_materials = (uint32_t)n_used;  // the records a render can touch
   dev.n_nodes_lds = n_nodes_lds;
   dev.n_spheres_lds = n_sph_lds;
   dev.n_aux_lds = n_aux_lds;
   dev.n_materials_lds = n_mat_lds;
-  dev.stack_cap = depth;
-  dev.stack_in_lds = stack_in_lds ? 1u : 0u;
-  dev.root = on_device ? tree.root : flat.root;
-  dev.bound = on_device ? tree.bound : flat.bound;
+  dev.stack_cap = wide ? wide_cache->stack_entries : depth;
+  dev.stack_in_lds = wide ? 1u : (stack_in_lds ? 1u : 0u);
+  dev.wide = wide ? 1u : 0u;
+  dev.lds_stack = lds_stack;
+  dev.root = wide ? 0u : (on_device ? tree.root : flat.root);
+  dev.bound = wide ? std::fmax(wide_cache->bound, on_device ? tree.bound : flat.bound) : (on_device ? tree.bound : flat.bound);
   bool single = true;  // the device builder makes one-sphere leaves only
   if (!on_device) {
     auto one = [](uint32_t ref) { return !(ref & kRefLeaf) || ref == kRefNone || ((ref >> 24) & 0x7fu) == 1u; };
@@ -316,7 +352,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, con
   dev.single_leaves = single ? 1u : 0u;
   *on_device_out = on_device;
   *depth_out = tree_depth;
-  *n_dev_nodes_out = n_dev_nodes;
+  *n_dev_nodes_out = n_final_nodes;
   return RT_OK;
 }
 
@@ -371,12 +407,54 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
   sc->n_spheres = n;
   sc->n_materials = nm;
 
-  // Material table, 32 bytes each (layout documented at scatter() in rt_device.h); the type
+  // The device's material table holds each distinct material once (the reference scene's 160 glass spheres
+  // share one record), those that spheres use first: only they are staged in LDS.
+  struct Key {
+    uint64_t w[5];
+    bool operator==(const Key& o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }
+  };
+  struct KeyHash {
+    size_t operator()(const Key& k) const {
+      uint64_t h = 0x9E3779B97F4A7C15ull;
+      for (uint64_t v : k.w) h = (h ^ v) * 0xD6E8FEB86659FD93ull + (h >> 29);
+      return (size_t)h;
+    }
+  };
+  auto key_of = [](const rt_material& m) {
+    Key k{};
+    k.w[0] = m.type;
+    if (m.type == RT_DIELECTRIC) {
+      std::memcpy(&k.w[1], &m.param, 8);
+    } else {
+      std::memcpy(&k.w[1], m.albedo, 24);
+      if (m.type == RT_METAL) std::memcpy(&k.w[4], &m.param, 8);
+    }
+    return k;
+  };
+  std::unordered_map<Key, uint32_t, KeyHash> seen;
+  std::vector<const rt_material*> table;
+  sc->table_index.assign(nm, 0xffffffffu);
+  auto place = [&](size_t m) {
+    if (sc->table_index[m] != 0xffffffffu) return;
+    auto it = seen.emplace(key_of(materials[m]), (uint32_t)table.size());
+    if (it.second) table.push_back(&materials[m]);
+    sc->table_index[m] = it.first->second;
+  };
+  std::vector<rt_sphere> placed(spheres, spheres + n);  // the spheres with their materials' table indices
+  for (size_t i = 0; i < n; ++i) {
+    place(spheres[i].material);
+    placed[i].material = sc->table_index[spheres[i].material];
+  }
+  const size_t n_used = table.size();
+  for (size_t m = 0; m < nm; ++m) place(m);  // materials no sphere uses: kept for rt_scatter_batch, never staged
+  const size_t n_table = table.size();
+
+  // Table records, 32 bytes each (layout documented at scatter() in rt_device.h); the type
   // travels with the material index in each sphere slot's shading word.
-  std::vector<double> mats(4 * nm, 0.0);
-  sc->material_type.resize(nm);
-  for (size_t i = 0; i < nm; ++i) {
-    const rt_material& m = materials[i];
+  std::vector<double> mats(4 * n_table, 0.0);
+  sc->material_type.resize(n_table);
+  for (size_t i = 0; i < n_table; ++i) {
+    const rt_material& m = *table[i];
     double* d = &mats[4 * i];
     sc->material_type[i] = (uint8_t)m.type;
     if (m.type == RT_DIELECTRIC) {
@@ -391,6 +469,7 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
       d[3] = m.type == RT_METAL ? m.param : 0.0;
     }
   }
+  spheres = placed.data();
 
   // The tree: built on the host with the reference's algorithm (once, then uploaded to every device), or on each
   // device (two or more spheres; a tree too deep for the traversal stack falls back to the host builder).
@@ -398,6 +477,7 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
   const size_t max_depth = (kLdsPerCu - lds_fixed_bytes() - 64 - 16 * 1024) / (kWorkgroup * 4);
   bool want_device = builder == RT_BUILD_DEVICE_LBVH && n >= 2;
   FlatBvh flat;
+  WideBvh wide_cache;
   bool have_flat = false;
   bool on_device = false;
   uint32_t tree_depth = 0;
@@ -415,7 +495,7 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
         have_flat = true;
       }
       bool od = false;
-      int rc = make_replica(*rp, spheres, n, nm, mats, sc->material_type, want_device, &flat, max_depth, &od, &tree_depth, &n_dev_nodes);
+      int rc = make_replica(*rp, spheres, n, n_table, n_used, mats, sc->material_type, want_device, &flat, max_depth, &wide_cache, &od, &tree_depth, &n_dev_nodes);
       if (rc) return rc;
       if (want_device && !od) {  // too deep: every replica takes the host tree
         want_device = false;
@@ -456,7 +536,7 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
   sc->info.n_nodes_in_lds = r0.dev.n_nodes_lds;
   sc->info.spheres_in_lds = (r0.dev.n_spheres_lds ? 1u : 0u) | (r0.dev.n_aux_lds ? 2u : 0u) | (r0.dev.n_materials_lds ? 4u : 0u);
   sc->info.device = (uint32_t)r0.device;
-  sc->info.device_bytes = n_dev_nodes * sizeof(DevNode) + n * sizeof(DevSphere) + n * sizeof(DevSphereAux) + nm * 32;
+  sc->info.device_bytes = n_dev_nodes * 64 + n * sizeof(DevSphere) + n * sizeof(DevSphereAux) + n_table * 32;  // both node kinds take 64 bytes
   sc->info.build_ms = build_ms;
   sc->info.lds_bytes = tree_lds_bytes(r0.dev);
   sc->info.n_devices = (uint32_t)R;
@@ -583,7 +663,12 @@ int plan_render(const Replica& rp, const CameraDev& cam, uint64_t seed, const rt
   P.inner_min = g_inner_min.load();
   P.both_min = g_both_min.load();
   P.leaf_min = g_leaf_min.load();
-  if (!P.sc.stack_in_lds) {
+  if (P.sc.wide) {  // the stack entries beyond those kept in LDS
+    if (P.sc.stack_cap > P.sc.lds_stack) {
+      P.sc.gstack_stride = (uint32_t)rp.num_cus * kWorkgroup;
+      L->gstack_bytes = (size_t)P.sc.gstack_stride * (P.sc.stack_cap - P.sc.lds_stack) * 4;
+    }
+  } else if (!P.sc.stack_in_lds) {
     P.sc.gstack_stride = (uint32_t)rp.num_cus * kWorkgroup;
     L->gstack_bytes = (size_t)P.sc.gstack_stride * P.sc.stack_cap * 4;
   }
@@ -928,10 +1013,11 @@ int rt_trace_batch(const rt_scene* sc, const double* org, const double* dir, siz
     RT_HIP(hipMemcpy(d_dir.p, dir, n * 24, hipMemcpyHostToDevice));
     SceneDev dev = rp.dev;
     DevBuf gstack;
-    if (!dev.stack_in_lds) {  // a tree too deep for LDS stacks: one column of global memory per thread of the launch
+    const uint32_t global_entries = dev.wide ? (dev.stack_cap > dev.lds_stack ? dev.stack_cap - dev.lds_stack : 0u) : (dev.stack_in_lds ? 0u : dev.stack_cap);
+    if (global_entries) {  // stack entries that do not live in LDS: one column of global memory per thread of the launch
       const size_t blocks = std::min<size_t>((n + kWorkgroup - 1) / kWorkgroup, (size_t)rp.num_cus);
       dev.gstack_stride = (uint32_t)(blocks * kWorkgroup);
-      RT_HIP(gstack.alloc((size_t)dev.gstack_stride * dev.stack_cap * 4));
+      RT_HIP(gstack.alloc((size_t)dev.gstack_stride * global_entries * 4));
       dev.gstack = gstack.as<uint32_t>();
     }
     RT_HIP(launch_trace_batch(dev, d_org.as<double>(), d_dir.as<double>(), n, t_min, t_max, d_prim.as<int32_t>(), d_t.as<double>(),
@@ -955,7 +1041,8 @@ int rt_scatter_batch(const rt_scene* sc, const uint32_t* material, const double*
     std::vector<uint32_t> tagged(n);  // material index with its type in the top two bits, as the kernels carry it
     for (size_t i = 0; i < n; ++i) {
       if (material[i] >= sc->n_materials) return fail(RT_ERR_INVALID, "rt_scatter_batch: material index out of range");
-      tagged[i] = material[i] | ((uint32_t)sc->material_type[material[i]] << 30);
+      const uint32_t at = sc->table_index[material[i]];
+      tagged[i] = at | ((uint32_t)sc->material_type[at] << 30);
     }
     const Replica& rp = *sc->reps[0];
     DeviceGuard g(rp.device);
@@ -1237,6 +1324,11 @@ int rt_debug_set(const char* name, double value) {
     }
     if (key == "force_global_stack") {
       g_force_global_stack.store(value != 0.0);
+      return RT_OK;
+    }
+    if (key == "wide_lds_stack") {
+      if (!(value >= 0.0 && value <= 30.0)) return fail(RT_ERR_INVALID, "rt_debug_set: wide_lds_stack must be in 0 .. 30");
+      g_wide_lds_stack.store((uint32_t)value);
       return RT_OK;
     }
     if (key == "force_staged_sum") {

@@ -341,6 +341,14 @@ struct TreeView {
   bool single_leaves;  // every leaf holds exactly one sphere
 };
 
+// Stack of the four-wide traversal: the first `k` entries of a lane's stack live in LDS, deeper ones (rare) in
+// a column of global memory.
+struct HybridStack {
+  lds_u32* l;   // entry e < k at l[e * kWorkgroup]
+  uint32_t* g;  // entry e >= k at g[(e - k) * gstride]
+  uint32_t k, gstride;
+};
+
 // Writes node i (global layout q0..q3) into its LDS slot.
 // kScaled (trees that are in LDS as a whole): references to inner nodes are stored as the byte
 // offset of the node in the LDS copy, so that following one needs no multiplication.
@@ -418,6 +426,7 @@ struct Trav {
   int best;
 };
 
+template <bool kWide = false>
 __device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D3 d, double t_max) {
   tr.o = o;
   tr.d = d;
@@ -425,9 +434,15 @@ __device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D
   tr.t_best = t_max;
   tr.tmaxf = (t_max < 3.0e38) ? f32_above(t_max) : __builtin_inff();
   // The copy must match the sign the node test sees, which is that of the f32 reciprocal.
-  tr.offx = tr.q.rx < 0.0f ? 16u : 0u;
-  tr.offy = tr.q.ry < 0.0f ? 48u : 32u;
-  tr.offz = tr.q.rz < 0.0f ? 80u : 64u;
+  if (kWide) {  // four-wide nodes: a mask per axis that picks the high planes as the near ones
+    tr.offx = tr.q.rx < 0.0f ? 0xffffffffu : 0u;
+    tr.offy = tr.q.ry < 0.0f ? 0xffffffffu : 0u;
+    tr.offz = tr.q.rz < 0.0f ? 0xffffffffu : 0u;
+  } else {
+    tr.offx = tr.q.rx < 0.0f ? 16u : 0u;
+    tr.offy = tr.q.ry < 0.0f ? 48u : 32u;
+    tr.offz = tr.q.rz < 0.0f ? 80u : 64u;
+  }
   tr.cur = tv.root;
   tr.sp = 0;
   tr.tos = kRefDone;  // popping the bottom entry ends the traversal
@@ -563,6 +578,135 @@ __device__ __forceinline__ uint32_t trav_inner_pair(Trav& tr, const TreeView& tv
   return 1u;
 }
 
+// ------------------------------------------------------- four-wide nodes ----
+// Scenes too large for LDS are walked through 64-byte nodes of up to four children whose boxes are 8-bit
+// offsets from a corner (WideNode in bvh_builder.h): q0 = (corner.xyz, step.x), q1 = (low planes x, y, z: child k
+// in byte k; step.y), q2 = (high planes; step.z), q3 = the four references.  A plane corner + (1024 + q) s is
+// crossed at
+//   t = (1024 + q) (s r) + (corner r - o r),
+// evaluated as fma(h, a, c): h the half-precision number 1024 + q (a byte permute puts the byte under the
+// exponent 0x64), a = s * rf (exact: s is a power of two) and c = fma(corner, rf, c_ray), where
+// c_ray = -(o r) -/+ e carries the ray's pad (ray_box_axis).  The extra rounding of c is within the pad:
+// 5 B |r| + 8 |o r| half-ulps are needed, 6 B |r| + 12 |o r| are there, B bounding every corner and plane.
+constexpr uint32_t kWideLdsStride = 80;  // bytes between nodes staged in LDS: an odd multiple of 16 spreads them over the banks
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+
+__device__ __forceinline__ lds_u32* hs_slot_l(const HybridStack& st, uint32_t e) { return st.l + e * kWorkgroup; }
+__device__ __forceinline__ void hs_store(const HybridStack& st, uint32_t e, uint32_t v) {
+  if (e < st.k)
+    *hs_slot_l(st, e) = v;
+  else
+    st.g[(size_t)(e - st.k) * st.gstride] = v;
+}
+__device__ __forceinline__ uint32_t hs_load(const HybridStack& st, uint32_t e) {
+  if (e < st.k) return *hs_slot_l(st, e);
+  return st.g[(size_t)(e - st.k) * st.gstride];
+}
+// The stack of the four-wide walk counts `sp` in entries; as in the two-wide walk the top lives in a register.
+__device__ __forceinline__ void trav_pop(Trav& tr, const HybridStack& st, uint32_t) {
+  tr.cur = tr.tos;
+  tr.sp = __builtin_elementwise_sub_sat(tr.sp, 1u);
+  tr.tos = hs_load(st, tr.sp);
+}
+__device__ __forceinline__ void trav_push(Trav& tr, const HybridStack& st, uint32_t ref) {
+  hs_store(st, tr.sp, tr.tos);
+  tr.sp += 1u;
+  tr.tos = ref;
+}
+// mask ? a : b, bit by bit
+__device__ __forceinline__ uint32_t pick_bits(uint32_t mask, uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+  return r;
+}
+// Bytes (0, 1) or (2, 3) of w as the two half-precision numbers 1024 + byte in one register.
+template <int kPair>
+__device__ __forceinline__ uint32_t halves_of_bytes(uint32_t w) {
+  uint32_t r;
+  asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(0x64646464u), "v"(w), "s"(kPair == 0 ? 0x04010400u : 0x04030402u));
+  return r;
+}
+// h * a + c with h the low (kHigh = 0) or high half of `halves` read as a half-precision number
+template <int kHigh>
+__device__ __forceinline__ float fma_half(uint32_t halves, float a, float c) {
+  float r;
+  if (kHigh)
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(halves), "v"(a), "v"(c));
+  else
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(halves), "v"(a), "v"(c));
+  return r;
+}
+// Entry and exit distances of children (2 kPair, 2 kPair + 1) of a node.
+template <int kPair>
+__device__ __forceinline__ void wide_pair(const Trav& tr, uint32_t nwx, uint32_t nwy, uint32_t nwz, uint32_t fwx, uint32_t fwy, uint32_t fwz,
+                                          float ax, float ay, float az, float cnx, float cny, float cnz, float cfx, float cfy, float cfz,
+                                          float tminf, float& tna, float& tnb, bool& ha, bool& hb) {
+  const uint32_t nx = halves_of_bytes<kPair>(nwx), ny = halves_of_bytes<kPair>(nwy), nz = halves_of_bytes<kPair>(nwz);
+  const uint32_t fx = halves_of_bytes<kPair>(fwx), fy = halves_of_bytes<kPair>(fwy), fz = halves_of_bytes<kPair>(fwz);
+  tna = max3_raw(fma_half<0>(nx, ax, cnx), fma_half<0>(ny, ay, cny), max_raw(fma_half<0>(nz, az, cnz), tminf));
+  tnb = max3_raw(fma_half<1>(nx, ax, cnx), fma_half<1>(ny, ay, cny), max_raw(fma_half<1>(nz, az, cnz), tminf));
+  const float tfa = min3_raw(fma_half<0>(fx, ax, cfx), fma_half<0>(fy, ay, cfy), min_raw(fma_half<0>(fz, az, cfz), tr.tmaxf));
+  const float tfb = min3_raw(fma_half<1>(fx, ax, cfx), fma_half<1>(fy, ay, cfy), min_raw(fma_half<1>(fz, az, cfz), tr.tmaxf));
+  ha = tna <= tfa;
+  hb = tnb <= tfb;
+}
+
+// One four-wide node: test the four child boxes, continue with the one entered first, set the others aside.
+__device__ __forceinline__ void trav_wide_step(Trav& tr, const TreeView& tv, const HybridStack& st, float tminf) {
+  f32x4 q0;
+  u32x4 q1, q2, refs;
+  if (tr.cur < tv.n_lds) {
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* p = (lds_char*)tv.lnodes + __umul24(tr.cur, kWideLdsStride);
+    q0 = *(lds_float4*)p;
+    q1 = *(lds_u32x4*)(p + 16);
+    q2 = *(lds_u32x4*)(p + 32);
+    refs = *(lds_u32x4*)(p + 48);
+  } else {
+    const f32x4* p = reinterpret_cast<const f32x4*>(tv.gnodes) + 4 * (size_t)tr.cur;
+    q0 = p[0];
+    q1 = *reinterpret_cast<const u32x4*>(p + 1);
+    q2 = *reinterpret_cast<const u32x4*>(p + 2);
+    refs = *reinterpret_cast<const u32x4*>(p + 3);
+  }
+  const float ax = q0.w * tr.q.rx, ay = __uint_as_float(q1.w) * tr.q.ry, az = __uint_as_float(q2.w) * tr.q.rz;
+  const float cnx = fmaf(q0.x, tr.q.rx, tr.q.nx.x), cfx = fmaf(q0.x, tr.q.rx, tr.q.nx.y);
+  const float cny = fmaf(q0.y, tr.q.ry, tr.q.ny.x), cfy = fmaf(q0.y, tr.q.ry, tr.q.ny.y);
+  const float cnz = fmaf(q0.z, tr.q.rz, tr.q.nz.x), cfz = fmaf(q0.z, tr.q.rz, tr.q.nz.y);
+  // the planes met first: the low ones for a ray travelling up the axis, the high ones otherwise
+  const uint32_t nwx = pick_bits(tr.offx, q2.x, q1.x), fwx = pick_bits(tr.offx, q1.x, q2.x);
+  const uint32_t nwy = pick_bits(tr.offy, q2.y, q1.y), fwy = pick_bits(tr.offy, q1.y, q2.y);
+  const uint32_t nwz = pick_bits(tr.offz, q2.z, q1.z), fwz = pick_bits(tr.offz, q1.z, q2.z);
+  float tn0, tn1, tn2, tn3;
+  bool h0, h1, h2, h3;
+  wide_pair<0>(tr, nwx, nwy, nwz, fwx, fwy, fwz, ax, ay, az, cnx, cny, cnz, cfx, cfy, cfz, tminf, tn0, tn1, h0, h1);
+  wide_pair<1>(tr, nwx, nwy, nwz, fwx, fwy, fwz, ax, ay, az, cnx, cny, cnz, cfx, cfy, cfz, tminf, tn2, tn3, h2, h3);
+  // a node has at least two children; the boxes of absent ones are inverted, and their reference makes sure
+  h2 = h2 && refs.z != kRefDone;
+  h3 = h3 && refs.w != kRefDone;
+  const float inf = __builtin_inff();
+  const float t0 = h0 ? tn0 : inf, t1 = h1 ? tn1 : inf, t2 = h2 ? tn2 : inf, t3 = h3 ? tn3 : inf;
+  const float m = min3_raw(t0, t1, min_raw(t2, t3));
+  // the child entered first (the lowest of equals); selects, not branches
+  const bool is0 = t0 == m, is1 = t1 == m, is2 = t2 == m;
+  const uint32_t first = is0 ? 0u : is1 ? 1u : is2 ? 2u : 3u;
+  const uint32_t next = is0 ? refs.x : is1 ? refs.y : is2 ? refs.z : refs.w;
+  // The others that are hit wait on the stack, pushed in the order 3, 2, 1, 0 (last pushed, first visited: the
+  // later children of a node come from the larger subtree that was opened up).  (Measured: storing to three slots
+  // unconditionally instead of these branches, and one generic load sequence for LDS and global nodes, were both slower.)
+  if (h3 && first != 3u) trav_push(tr, st, refs.w);
+  if (h2 && first != 2u) trav_push(tr, st, refs.z);
+  if (h1 && first != 1u) trav_push(tr, st, refs.y);
+  if (h0 && !is0) trav_push(tr, st, refs.x);
+  if (h0 || h1 || h2 || h3) {
+    tr.cur = next;
+  } else {
+    trav_pop(tr, st, 0u);
+  }
+}
+
 // One leaf: Sphere::hit (src/sphere.rs:29-48) for each of its spheres.  The
 // direction has unit length, so the reference's a = |d|^2 is taken as 1.
 // Sphere::hit (src/sphere.rs:29-48) for the sphere in `slot`.  The direction has unit length, so
@@ -620,6 +764,19 @@ __device__ __forceinline__ void trav_run(Trav& tr, const TreeView& tv, StackPtr 
       ++n_steps;
     }
     if (tr.cur != kRefDone) trav_leaf_step<kAllLds>(tr, tv, stack, stride, t_min, n_tests);
+  }
+}
+
+// The same over the four-wide tree.
+__device__ __forceinline__ void trav_run_wide(Trav& tr, const TreeView& tv, const HybridStack& st, double t_min, uint32_t& n_steps,
+                                              uint32_t& n_tests) {
+  const float tminf = f32_below(t_min);
+  while (tr.cur != kRefDone) {
+    while (!(tr.cur & kRefLeaf)) {
+      trav_wide_step(tr, tv, st, tminf);
+      ++n_steps;
+    }
+    if (tr.cur != kRefDone) trav_leaf_step<false>(tr, tv, st, 0u, t_min, n_tests);
   }
 }
 

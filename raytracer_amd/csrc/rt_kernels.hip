@@ -15,11 +15,11 @@ struct LdsImage {
   lds_u32* stack_base;
 };
 
-template <bool kAllLds>
+template <bool kAllLds, bool kWide = false>
 __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const CameraDev* cam, float4* smem, uint32_t wg) {
   lds_double* lcam = (lds_double*)smem;
   lds_float4* lnodes = (lds_float4*)(lcam + CAM_DOUBLES);
-  lds_double2* lsph = (lds_double2*)(lnodes + kLdsNodeQuads * sc.n_nodes_lds);
+  lds_double2* lsph = (lds_double2*)(lnodes + (kWide ? kWideLdsStride / 16 : kLdsNodeQuads) * sc.n_nodes_lds);
   lds_double2* laux = lsph + 2 * sc.n_spheres_lds;
   lds_double2* lmat = laux + sc.n_aux_lds;
   lds_u32* stack_base = (lds_u32*)(lmat + 2 * sc.n_materials_lds);
@@ -32,7 +32,11 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
     const double* src = k < 3 ? cam->center : k < 6 ? cam->pixel00 : k < 9 ? cam->du : k < 12 ? cam->dv : k < 15 ? cam->disk_u : cam->disk_v;
     lcam[k] = src[k % 3];
   }
-  for (uint32_t i = threadIdx.x; i < sc.n_nodes_lds; i += wg) stage_node<kAllLds>(lnodes, i, gn[4 * i], gn[4 * i + 1], gn[4 * i + 2], gn[4 * i + 3]);
+  if (kWide) {  // four-wide nodes are staged as they are, 80 bytes apart
+    for (uint32_t i = threadIdx.x; i < 4 * sc.n_nodes_lds; i += wg) lnodes[(kWideLdsStride / 16) * (i >> 2) + (i & 3u)] = gn[i];
+  } else {
+    for (uint32_t i = threadIdx.x; i < sc.n_nodes_lds; i += wg) stage_node<kAllLds>(lnodes, i, gn[4 * i], gn[4 * i + 1], gn[4 * i + 2], gn[4 * i + 3]);
+  }
   for (uint32_t i = threadIdx.x; i < 2 * sc.n_spheres_lds; i += wg) lsph[i] = gs[i];
   for (uint32_t i = threadIdx.x; i < sc.n_aux_lds; i += wg) laux[i] = ga[i];
   for (uint32_t i = threadIdx.x; i < 2 * sc.n_materials_lds; i += wg) lmat[i] = gm[i];
@@ -59,22 +63,24 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
 }
 
 // ------------------------------------------------------------ trace batch ----
-template <bool kAllLds, bool kGStack>
+template <bool kAllLds, bool kGStack, bool kWide = false>
 __global__ __launch_bounds__(kWorkgroup) void trace_batch_kernel(SceneDev sc, const double* __restrict__ org, const double* __restrict__ dir,
                                                                  size_t n, double t_min, double t_max, int32_t* __restrict__ prim,
                                                                  double* __restrict__ t_out, double* __restrict__ normal,
                                                                  uint8_t* __restrict__ front, uint32_t* __restrict__ counts) {
   extern __shared__ float4 smem[];
-  const LdsImage im = stage_scene<kAllLds>(sc, nullptr, smem, kWorkgroup);
+  const LdsImage im = stage_scene<kAllLds, kWide>(sc, nullptr, smem, kWorkgroup);
   const TreeView& tv = im.tv;
   const uint32_t gtid = blockIdx.x * kWorkgroup + threadIdx.x;
   for (size_t i = (size_t)blockIdx.x * kWorkgroup + threadIdx.x; i < n; i += (size_t)gridDim.x * kWorkgroup) {
     D3 o = d3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
     D3 d = normalize(d3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));  // Ray::new, src/ray.rs:16-23
     Trav tr;
-    trav_begin(tr, tv, o, d, t_max);
+    trav_begin<kWide>(tr, tv, o, d, t_max);
     uint32_t n_steps = 0, n_tests = 0;
-    if constexpr (kGStack)
+    if constexpr (kWide)
+      trav_run_wide(tr, tv, HybridStack{im.stack_base + threadIdx.x, sc.gstack + gtid, sc.lds_stack, sc.gstack_stride}, t_min, n_steps, n_tests);
+    else if constexpr (kGStack)
       trav_run<kAllLds>(tr, tv, sc.gstack + gtid, sc.gstack_stride, t_min, n_steps, n_tests);
     else
       trav_run<kAllLds>(tr, tv, im.stack_base + threadIdx.x, kWorkgroup, t_min, n_steps, n_tests);
@@ -213,14 +219,16 @@ __device__ __forceinline__ uint32_t count_mask(unsigned long long m) {
 #define RTA_T1(k) \
   if (kProf) prof_cycles[k] += __builtin_amdgcn_s_memtime() - t0_;
 
-template <bool kAllLds, bool kProf, bool kGStack, bool kSingle>
+template <bool kAllLds, bool kProf, bool kGStack, bool kSingle, bool kWide = false>
 __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  // 16 waves per CU: at most 128 VGPRs
   extern __shared__ float4 smem[];
-  const LdsImage im = stage_scene<kAllLds>(P.sc, &P.cam, smem, kWorkgroup);
+  const LdsImage im = stage_scene<kAllLds, kWide>(P.sc, &P.cam, smem, kWorkgroup);
   const TreeView& tv = im.tv;
   // The lane's stack column is recomputed where it is used (one add), not kept in a register.
   auto stack_of_lane = [&]() {
-    if constexpr (kGStack)
+    if constexpr (kWide)
+      return HybridStack{im.stack_base + threadIdx.x, P.sc.gstack + (blockIdx.x * kWorkgroup + threadIdx.x), P.sc.lds_stack, P.sc.gstack_stride};
+    else if constexpr (kGStack)
       return P.sc.gstack + (blockIdx.x * kWorkgroup + threadIdx.x);
     else
       return im.stack_base + threadIdx.x;
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           if (scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd)) {  // None = absorbed, src/camera.rs:108-110
             thr = thr * att;
             if (--depth_left != 0) {  // depth exhausted: the path contributes nothing (src/camera.rs:99-101)
-              trav_begin(tr, tv, h.p, nd, __builtin_inf());  // HitRecord::ray, src/hit.rs:29-31
+              trav_begin<kWide>(tr, tv, h.p, nd, __builtin_inf());  // HitRecord::ray, src/hit.rs:29-31
               ended = false;
             }
           }
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
             camera_ray(im.cam, P.cam.width, P.cam.defocus != 0, P.seed_lo, P.seed_hi, RTA_I, RTA_J, s, o, d);
             thr = d3(1.0, 1.0, 1.0);
             depth_left = P.cam.max_depth;
-            trav_begin(tr, tv, o, d, __builtin_inf());
+            trav_begin<kWide>(tr, tv, o, d, __builtin_inf());
           }
         }
       }
@@ -388,7 +396,13 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           RTA_T0()
           if (!(tr.cur & kRefLeaf)) {
             RTA_PROF(BLK_INNER)
-            const uint32_t steps = trav_inner_pair<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
+            uint32_t steps;
+            if constexpr (kWide) {
+              trav_wide_step(tr, tv, RTA_STACK, tminf);
+              steps = 1u;
+            } else {
+              steps = trav_inner_pair<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
+            }
             if (kProf) n_steps += steps;
           }
           RTA_T1(BLK_INNER)
@@ -444,7 +458,10 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
         RTA_T0()
         if (!(tr.cur & kRefLeaf)) {
           RTA_PROF(BLK_INNER)
-          trav_inner_step<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
+          if constexpr (kWide)
+            trav_wide_step(tr, tv, RTA_STACK, tminf);
+          else
+            trav_inner_step<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
           if (kProf) ++n_steps;
         }
         RTA_T1(BLK_INNER)
@@ -589,8 +606,10 @@ hipError_t static_scratch(int device, void** ptr, size_t* bytes) {
 
 // --------------------------------------------------------------- launchers ----
 size_t lds_node_bytes() { return kLdsNodeQuads * 16; }
+size_t lds_wide_node_bytes() { return kWideLdsStride; }
 size_t lds_fixed_bytes() { return CAM_DOUBLES * 8; }
 size_t tree_lds_bytes(const SceneDev& sc) {
+  if (sc.wide) return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * kWideLdsStride + (size_t)sc.lds_stack * kWorkgroup * 4;
   return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * lds_node_bytes() + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
          (size_t)sc.n_materials_lds * 32 + (sc.stack_in_lds ? (size_t)sc.stack_cap * kWorkgroup * 4 : 0);
 }
@@ -608,8 +627,9 @@ hipError_t launch_trace_batch(const SceneDev& sc, const double* org, const doubl
                               double* t, double* normal, uint8_t* front, uint32_t* counts, int max_blocks, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   size_t lds = tree_lds_bytes(sc);
-  auto fn = sc.stack_in_lds ? (all_in_lds(sc) ? trace_batch_kernel<true, false> : trace_batch_kernel<false, false>)
-                            : (all_in_lds(sc) ? trace_batch_kernel<true, true> : trace_batch_kernel<false, true>);
+  // A scene is either wholly in LDS (two-wide tree) or walked through the four-wide tree.
+  if (!sc.wide && !all_in_lds(sc)) return hipErrorInvalidValue;
+  auto fn = sc.wide ? trace_batch_kernel<false, false, true> : sc.stack_in_lds ? trace_batch_kernel<true, false> : trace_batch_kernel<true, true>;
   hipError_t e = allow_lds((const void*)fn, lds);
   if (e != hipSuccess) return e;
   size_t blocks = (n + kWorkgroup - 1) / kWorkgroup;
@@ -643,23 +663,23 @@ hipError_t launch_primary_rays(const CameraDev& cam, uint64_t seed, const uint32
   return hipGetLastError();
 }
 
-// The variant for the scene: tree wholly in LDS or not, stacks in LDS or in global memory, leaves of one
-// sphere each or not; the instrumented form exists for one-sphere leaves and LDS stacks only.
-template <bool kAllLds, bool kGStack>
-static void (*pick_render(bool single, bool profile))(RenderParams) {
-  if constexpr (!kGStack) {
-    if (profile && single) return render_kernel<kAllLds, true, false, true>;
-  }
-  return single ? render_kernel<kAllLds, false, kGStack, true> : render_kernel<kAllLds, false, kGStack, false>;
-}
+// The variant for the scene: two-wide tree wholly in LDS (stacks in LDS, or in global memory for very deep
+// trees) or four-wide tree; leaves of one sphere each or not; the instrumented form exists for one-sphere
+// leaves and LDS stacks only.
 hipError_t launch_render(const RenderParams& P, int blocks, bool profile, hipStream_t stream) {
   size_t lds = tree_lds_bytes(P.sc);
   const bool single = P.sc.single_leaves != 0u;
   void (*fn)(RenderParams);
-  if (P.sc.stack_in_lds)
-    fn = all_in_lds(P.sc) ? pick_render<true, false>(single, profile) : pick_render<false, false>(single, profile);
+  if (P.sc.wide)
+    fn = profile && single ? render_kernel<false, true, false, true, true>
+         : single          ? render_kernel<false, false, false, true, true>
+                           : render_kernel<false, false, false, false, true>;
+  else if (!all_in_lds(P.sc))
+    return hipErrorInvalidValue;
+  else if (P.sc.stack_in_lds)
+    fn = profile && single ? render_kernel<true, true, false, true> : single ? render_kernel<true, false, false, true> : render_kernel<true, false, false, false>;
   else
-    fn = all_in_lds(P.sc) ? pick_render<true, true>(single, profile) : pick_render<false, true>(single, profile);
+    fn = single ? render_kernel<true, false, true, true> : render_kernel<true, false, true, false>;
   hipError_t e = allow_lds((const void*)fn, lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kWorkgroup), lds, stream, P);

@@ -32,6 +32,10 @@ struct SceneDev {
   uint32_t root;            // ref of the root: inner node 0, a leaf ref, or 0xffffffff for an empty scene
   uint32_t single_leaves;   // 1: every leaf holds exactly one sphere (the leaf test then needs no loop)
   float bound;              // largest |coordinate| of any box plane in the tree
+  // Four-wide tree (scenes that do not fit in LDS): nodes are 64-byte WideNode records, n_nodes_lds of them staged
+  // in LDS; the first lds_stack entries of a lane's stack live in LDS, the other stack_cap - lds_stack in gstack.
+  uint32_t wide;
+  uint32_t lds_stack;
 };
 
 struct CameraDev {
@@ -71,6 +75,7 @@ constexpr int kRenderCounters = 18;
 size_t tree_lds_bytes(const SceneDev& sc);
 // LDS footprint of one staged node / of the fixed part (camera constants).
 size_t lds_node_bytes();
+size_t lds_wide_node_bytes();
 size_t lds_fixed_bytes();
 
 // All launchers enqueue on `stream` and return the launch status; pointers are device pointers.

@@ -664,3 +664,42 @@ def test_full_resolution_frame_properties(world):
     mean = whole.mean() / 6.0
     assert abs(mean - 0.419) < 0.004
     assert abs(st["rays"] / st["samples"] - 2.853) < 0.01  # mean path length of this scene and camera
+
+
+def test_material_table_shares_equal_materials(oracle, rtiow):
+    # Equal materials share one device record and materials no sphere uses are never staged; neither changes a result.
+    spheres, materials = rtiow
+    rng = np.random.default_rng(12)
+    # every material three times, spheres pointed at random copies, plus many materials nobody uses
+    unused = np.zeros(5000, dtype=rt.MATERIAL_DTYPE)
+    unused["type"] = rng.integers(0, 3, 5000)
+    unused["albedo"] = rng.random((5000, 3))
+    unused["param"] = np.where(unused["type"] == 2, 1.5, rng.random(5000))
+    many = np.concatenate([materials, materials, unused, materials])
+    moved = spheres.copy()
+    moved["material"] = spheres["material"] + rng.choice([0, len(materials), 2 * len(materials) + 5000], len(spheres))
+    a, b = rt.BVH(spheres, materials), rt.BVH(moved, many)
+    assert b.info()["spheres_in_lds"] == 7  # still wholly in LDS
+    cam = rt.config_rtiow(image_width=96, samples_per_pixel=8, max_depth=50).camera()
+    ia, sa = cam.render_sum(a, seed=6)
+    ib, sb = cam.render_sum(b, seed=6)
+    assert np.array_equal(ia, ib) and sa["rays"] == sb["rays"]
+    # scatter through a material that only exists in the second scene's unused part
+    n = 512
+    mat = (2 * len(materials) + rng.integers(0, 5000, n)).astype(np.uint32)
+    normal = rng.normal(size=(n, 3))
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    in_dir = rng.normal(size=(n, 3))
+    normal[(in_dir * normal).sum(axis=1) > 0] *= -1
+    front, p, u = rng.random(n) < 0.5, rng.uniform(-5, 5, (n, 3)), rng.random((n, 2))
+    gs, ga, gd = b.scatter_batch(mat, in_dir, p, normal, front, u)
+    ws, wa, wd = oracle.scatter_batch(many.view(oracle.MATERIAL_DTYPE), mat, in_dir, p, normal, front, u)
+    assert np.array_equal(gs, ws) and np.abs(ga - wa).max() <= 1e-12 and np.abs(gd - wd).max() <= 1e-9
+    # one sphere and a crowd of unused materials: the tree is a single leaf
+    lone = rt.BVH(spheres[1:2].copy(), many)
+    one = rt.BVH(spheres[1:2].copy(), materials)
+    il, _ = cam.render_sum(lone, seed=2)
+    io, _ = cam.render_sum(one, seed=2)
+    assert np.array_equal(il, io)
+    for w in (a, b, lone, one):
+        w.close()

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Builds a variant of the library with extra compiler flags for A/B runs in one GPU call:
+#   tools/build_variant.sh NAME -DFLAG ...   ->  raytracer_amd/variants/libNAME.so   (use with RAYTRACER_AMD_LIB)
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+NAME=$1; shift
+mkdir -p "$R/raytracer_amd/variants"
+cd "$R/raytracer_amd/csrc"
+/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -I../../include -I. -Wall -fno-slp-vectorize "$@" -c rt_kernels.hip -o /tmp/rt_kernels_$NAME.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/raytracer_amd/variants/lib$NAME.so" bvh_builder.o rt_host.o rt_api.o /tmp/rt_kernels_$NAME.o rt_build.o
+echo built "$R/raytracer_amd/variants/lib$NAME.so"
