@@ -483,47 +483,12 @@ WideBvh collapse_wide(const DevNode* nodes, size_t n_nodes) {
       ch[n++] = two[1];
     }
     WideNode node{};
-    for (int a = 0; a < 3; ++a) {
-      float lo = ch[0].lo[a], hi = ch[0].hi[a];
-      for (int k = 1; k < n; ++k) {
-        lo = std::fmin(lo, ch[k].lo[a]);
-        hi = std::fmax(hi, ch[k].hi[a]);
-      }
-      // the smallest power of two s with 255 s >= extent (all in double: exact for f32 inputs); one step up
-      // if rounding the corner down to f32 makes the extent from it exceed that
-      const double extent = (double)hi - (double)lo;
-      int e = -100;
-      if (extent > 0.0) {
-        int ex;
-        const double m = std::frexp(extent / 255.0, &ex);  // extent / 255 = m 2^ex, m in [0.5, 1)
-        e = m == 0.5 ? ex - 1 : ex;
-        if (e < -100) e = -100;
-      }
-      double s, base;
-      float corner;
-      for (;; ++e) {
-        s = std::ldexp(1.0, e);
-        corner = round_down((double)lo - 1024.0 * s);
-        base = (double)corner + 1024.0 * s;  // plane of q = 0; at or below lo
-        if (std::ceil(((double)hi - base) / s) <= 255.0) break;
-      }
-      (a == 0 ? node.origin_x : a == 1 ? node.origin_y : node.origin_z) = corner;
-      (a == 0 ? node.step_x : a == 1 ? node.step_y : node.step_z) = (float)s;
-      bound = std::fmax(bound, std::fabs((double)corner));
-      uint32_t ql = 0, qh = 0;
+    for (int a = 0; a < 3; ++a)
       for (int k = 0; k < 4; ++k) {
-        uint32_t l = 255, h = 0;  // absent child: inverted
-        if (k < n) {
-          l = (uint32_t)std::min(255.0, std::floor(((double)ch[k].lo[a] - base) / s));
-          h = (uint32_t)std::min(255.0, std::ceil(((double)ch[k].hi[a] - base) / s));
-          bound = std::fmax(bound, std::fmax(std::fabs(base + l * s), std::fabs(base + h * s)));
-        }
-        ql |= l << (8 * k);
-        qh |= h << (8 * k);
+        node.planes[2 * a][k] = k < n ? ch[k].lo[a] : std::numeric_limits<float>::infinity();
+        node.planes[2 * a + 1][k] = k < n ? ch[k].hi[a] : -std::numeric_limits<float>::infinity();
+        if (k < n) bound = std::fmax(bound, std::fmax(std::fabs((double)ch[k].lo[a]), std::fabs((double)ch[k].hi[a])));
       }
-      node.qlo[a] = ql;
-      node.qhi[a] = qh;
-    }
     for (int k = 0; k < 4; ++k) {
       if (k >= n) {
         node.ref[k] = kRefNone;

@@ -71,23 +71,18 @@ struct FlatBvh {
 
 FlatBvh flatten_bvh(const HostBvh& bvh, const rt_sphere* spheres, size_t n);
 
-// 64-byte node of the four-wide tree that scenes too large for LDS are walked through: up to four
-// children whose boxes are stored as 8-bit offsets from a corner below the node's own, so that one 64-byte
-// fetch decides four children (half the bytes and half the dependent fetches per ray of the two-wide nodes).
-//   plane of child k on axis a = origin[a] + (1024 + q) * step[a],  q = byte k of qlo[a] / qhi[a]
-// (the kernels widen a byte to the half-precision number 1024 + q with one byte permute, which a mixed-precision
-// multiply-add then takes as it is; the 1024 steps are taken off the corner here).  step is a power of two; qlo
-// is rounded down and qhi up, so a child's box only grows.  ref: as in DevNode; a child that does not exist has
-// ref kRefNone and an inverted box.
+// 128-byte node of the four-wide tree that scenes too large for LDS are walked through: the f32 boxes
+// (rounded outwards) of up to four children, so that one fetch decides four children and a ray makes half
+// as many dependent fetches as through the two-wide nodes.  Per axis the four low planes and the four high
+// planes sit in separate 16-byte words (x low, x high, y low, y high, z low, z high): a lane reads the word it
+// meets first and the word it meets last by address, with no per-plane min/max.  ref: as in DevNode; a child
+// that does not exist has ref kRefNone and an inverted, infinite box.
 struct WideNode {
-  float origin_x, origin_y, origin_z, step_x;
-  uint32_t qlo[3];   // per axis: the four children's low planes, child k in byte k
-  float step_y;
-  uint32_t qhi[3];
-  float step_z;
+  float planes[6][4];
   uint32_t ref[4];
+  uint32_t pad[4];
 };
-static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
+static_assert(sizeof(WideNode) == 128, "WideNode must be 128 bytes");
 struct WideBvh {
   std::vector<WideNode> nodes;  // breadth-first: any prefix is the top of the tree; node 0 is the root
   uint32_t depth = 0;           // levels of wide nodes

@@ -111,6 +111,8 @@ std::atomic<bool> g_force_global_stack{false};
 std::atomic<bool> g_force_staged_sum{false};
 // Entries of a lane's traversal stack that the four-wide walk keeps in LDS (deeper ones go to global memory).
 std::atomic<uint32_t> g_wide_lds_stack{8};
+// Test hook: scenes created while this is set are walked through the four-wide tree even if they fit in LDS two-wide.
+std::atomic<bool> g_force_wide{false};
 
 // Partial sums of an allocating render call never exceed this; the sample range is cut into fewer chunks instead.
 constexpr uint64_t kWorkspaceLimit = 4ull << 30;
@@ -287,7 +289,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   // A scene that fits in LDS as a whole is walked through its two-wide tree; any other through the four-wide
   // tree with quantised boxes (half the bytes per ray), collapsed here from the two-wide nodes.
   const bool fits = n_nodes_lds == n_dev_nodes && n_sph_lds == n && n_aux_lds == n && n_mat_lds == n_used;
-  const bool wide = !fits && n_dev_nodes > 0;
+  const bool wide = (!fits || g_force_wide.load()) && n_dev_nodes > 0;
   uint32_t lds_stack = 0;
   size_t n_final_nodes = n_dev_nodes;
   if (wide) {
@@ -308,8 +310,19 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
     n_final_nodes = wb.nodes.size();
     lds_stack = g_force_global_stack.load() ? 0u : std::min<uint32_t>(wb.stack_entries, g_wide_lds_stack.load());
     const size_t wide_room = kLdsPerCu - reserve - (size_t)lds_stack * kWorkgroup * 4;
-    n_nodes_lds = (uint32_t)std::min(n_final_nodes, wide_room / lds_wide_node_bytes());
+    size_t wide_left = wide_room;
+    n_nodes_lds = (uint32_t)std::min(n_final_nodes, wide_left / lds_wide_node_bytes());
+    wide_left -= n_nodes_lds * lds_wide_node_bytes();
     n_sph_lds = n_aux_lds = n_mat_lds = 0;
+    if (n_nodes_lds == n_final_nodes && sph_bytes <= wide_left) {  // room to spare: the spheres, their shading data, the materials
+      n_sph_lds = (uint32_t)n;
+      wide_left -= sph_bytes;
+      if (aux_bytes <= wide_left) {
+        n_aux_lds = (uint32_t)n;
+        wide_left -= aux_bytes;
+        if (used_mat_bytes <= wide_left) n_mat_lds = (uint32_t)n_used;
+      }
+    }
     RT_HIP(hipMalloc(&rp.d_nodes, n_final_nodes * sizeof(WideNode)));
     RT_HIP(hipMemcpy(rp.d_nodes, wb.nodes.data(), n_final_nodes * sizeof(WideNode), hipMemcpyHostToDevice));
   } else if (!on_device) {
@@ -1324,6 +1337,10 @@ int rt_debug_set(const char* name, double value) {
     }
     if (key == "force_global_stack") {
       g_force_global_stack.store(value != 0.0);
+      return RT_OK;
+    }
+    if (key == "force_wide") {
+      g_force_wide.store(value != 0.0);
       return RT_OK;
     }
     if (key == "wide_lds_stack") {

@@ -434,10 +434,10 @@ __device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D
   tr.t_best = t_max;
   tr.tmaxf = (t_max < 3.0e38) ? f32_above(t_max) : __builtin_inff();
   // The copy must match the sign the node test sees, which is that of the f32 reciprocal.
-  if (kWide) {  // four-wide nodes: a mask per axis that picks the high planes as the near ones
-    tr.offx = tr.q.rx < 0.0f ? 0xffffffffu : 0u;
-    tr.offy = tr.q.ry < 0.0f ? 0xffffffffu : 0u;
-    tr.offz = tr.q.rz < 0.0f ? 0xffffffffu : 0u;
+  if (kWide) {  // four-wide nodes: per axis, the byte offset of the word of planes met first
+    tr.offx = tr.q.rx < 0.0f ? 16u : 0u;
+    tr.offy = tr.q.ry < 0.0f ? 16u : 0u;
+    tr.offz = tr.q.rz < 0.0f ? 16u : 0u;
   } else {
     tr.offx = tr.q.rx < 0.0f ? 16u : 0u;
     tr.offy = tr.q.ry < 0.0f ? 48u : 32u;
@@ -579,16 +579,13 @@ __device__ __forceinline__ uint32_t trav_inner_pair(Trav& tr, const TreeView& tv
 }
 
 // ------------------------------------------------------- four-wide nodes ----
-// Scenes too large for LDS are walked through 64-byte nodes of up to four children whose boxes are 8-bit
-// offsets from a corner (WideNode in bvh_builder.h): q0 = (corner.xyz, step.x), q1 = (low planes x, y, z: child k
-// in byte k; step.y), q2 = (high planes; step.z), q3 = the four references.  A plane corner + (1024 + q) s is
-// crossed at
-//   t = (1024 + q) (s r) + (corner r - o r),
-// evaluated as fma(h, a, c): h the half-precision number 1024 + q (a byte permute puts the byte under the
-// exponent 0x64), a = s * rf (exact: s is a power of two) and c = fma(corner, rf, c_ray), where
-// c_ray = -(o r) -/+ e carries the ray's pad (ray_box_axis).  The extra rounding of c is within the pad:
-// 5 B |r| + 8 |o r| half-ulps are needed, 6 B |r| + 12 |o r| are there, B bounding every corner and plane.
-constexpr uint32_t kWideLdsStride = 80;  // bytes between nodes staged in LDS: an odd multiple of 16 spreads them over the banks
+// Scenes too large for LDS are walked through 128-byte nodes holding the f32 boxes of up to four children
+// (WideNode in bvh_builder.h): per axis one 16-byte word of the four low planes and one of the four high planes,
+// then the four references.  A lane reads, per axis, the word it meets first and the word it meets last (by
+// address: tr.offx/y/z is 16 where the ray travels down the axis), so the test needs no per-plane min/max, and
+// the planes go through the same padded multiply-add as those of the two-wide nodes.
+constexpr uint32_t kWideLdsStride = 112;  // bytes between nodes staged in LDS (the padding is not staged): an odd multiple of 16 spreads them over the banks
+constexpr uint32_t kWideGlobalQuads = 8, kWideStagedQuads = 7;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
@@ -615,77 +612,45 @@ __device__ __forceinline__ void trav_push(Trav& tr, const HybridStack& st, uint3
   tr.sp += 1u;
   tr.tos = ref;
 }
-// mask ? a : b, bit by bit
-__device__ __forceinline__ uint32_t pick_bits(uint32_t mask, uint32_t a, uint32_t b) {
-  uint32_t r;
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
-  return r;
-}
-// Bytes (0, 1) or (2, 3) of w as the two half-precision numbers 1024 + byte in one register.
-template <int kPair>
-__device__ __forceinline__ uint32_t halves_of_bytes(uint32_t w) {
-  uint32_t r;
-  asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(0x64646464u), "v"(w), "s"(kPair == 0 ? 0x04010400u : 0x04030402u));
-  return r;
-}
-// h * a + c with h the low (kHigh = 0) or high half of `halves` read as a half-precision number
-template <int kHigh>
-__device__ __forceinline__ float fma_half(uint32_t halves, float a, float c) {
-  float r;
-  if (kHigh)
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(halves), "v"(a), "v"(c));
-  else
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(halves), "v"(a), "v"(c));
-  return r;
-}
-// Entry and exit distances of children (2 kPair, 2 kPair + 1) of a node.
-template <int kPair>
-__device__ __forceinline__ void wide_pair(const Trav& tr, uint32_t nwx, uint32_t nwy, uint32_t nwz, uint32_t fwx, uint32_t fwy, uint32_t fwz,
-                                          float ax, float ay, float az, float cnx, float cny, float cnz, float cfx, float cfy, float cfz,
-                                          float tminf, float& tna, float& tnb, bool& ha, bool& hb) {
-  const uint32_t nx = halves_of_bytes<kPair>(nwx), ny = halves_of_bytes<kPair>(nwy), nz = halves_of_bytes<kPair>(nwz);
-  const uint32_t fx = halves_of_bytes<kPair>(fwx), fy = halves_of_bytes<kPair>(fwy), fz = halves_of_bytes<kPair>(fwz);
-  tna = max3_raw(fma_half<0>(nx, ax, cnx), fma_half<0>(ny, ay, cny), max_raw(fma_half<0>(nz, az, cnz), tminf));
-  tnb = max3_raw(fma_half<1>(nx, ax, cnx), fma_half<1>(ny, ay, cny), max_raw(fma_half<1>(nz, az, cnz), tminf));
-  const float tfa = min3_raw(fma_half<0>(fx, ax, cfx), fma_half<0>(fy, ay, cfy), min_raw(fma_half<0>(fz, az, cfz), tr.tmaxf));
-  const float tfb = min3_raw(fma_half<1>(fx, ax, cfx), fma_half<1>(fy, ay, cfy), min_raw(fma_half<1>(fz, az, cfz), tr.tmaxf));
-  ha = tna <= tfa;
-  hb = tnb <= tfb;
-}
-
 // One four-wide node: test the four child boxes, continue with the one entered first, set the others aside.
 __device__ __forceinline__ void trav_wide_step(Trav& tr, const TreeView& tv, const HybridStack& st, float tminf) {
-  f32x4 q0;
-  u32x4 q1, q2, refs;
+  // tr.offx/y/z: 16 where the ray travels down the axis (its near planes are the high ones), else 0
+  f32x4 NX, FX, NY, FY, NZ, FZ;
+  u32x4 refs;
   if (tr.cur < tv.n_lds) {
     typedef __attribute__((address_space(3))) char lds_char;
     lds_char* p = (lds_char*)tv.lnodes + __umul24(tr.cur, kWideLdsStride);
-    q0 = *(lds_float4*)p;
-    q1 = *(lds_u32x4*)(p + 16);
-    q2 = *(lds_u32x4*)(p + 32);
-    refs = *(lds_u32x4*)(p + 48);
+    NX = *(lds_float4*)(p + tr.offx);
+    FX = *(lds_float4*)(p + (tr.offx ^ 16u));
+    NY = *(lds_float4*)(p + 32u + tr.offy);
+    FY = *(lds_float4*)(p + 32u + (tr.offy ^ 16u));
+    NZ = *(lds_float4*)(p + 64u + tr.offz);
+    FZ = *(lds_float4*)(p + 64u + (tr.offz ^ 16u));
+    refs = *(lds_u32x4*)(p + 96);
   } else {
-    const f32x4* p = reinterpret_cast<const f32x4*>(tv.gnodes) + 4 * (size_t)tr.cur;
-    q0 = p[0];
-    q1 = *reinterpret_cast<const u32x4*>(p + 1);
-    q2 = *reinterpret_cast<const u32x4*>(p + 2);
-    refs = *reinterpret_cast<const u32x4*>(p + 3);
+    const char* base = reinterpret_cast<const char*>(tv.gnodes);
+    const uint32_t at = tr.cur * 128u;
+    NX = *reinterpret_cast<const f32x4*>(base + (size_t)(at + tr.offx));
+    FX = *reinterpret_cast<const f32x4*>(base + (size_t)(at + (tr.offx ^ 16u)));
+    NY = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 32u + tr.offy));
+    FY = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 32u + (tr.offy ^ 16u)));
+    NZ = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 64u + tr.offz));
+    FZ = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 64u + (tr.offz ^ 16u)));
+    refs = *reinterpret_cast<const u32x4*>(base + (size_t)(at + 96u));
   }
-  const float ax = q0.w * tr.q.rx, ay = __uint_as_float(q1.w) * tr.q.ry, az = __uint_as_float(q2.w) * tr.q.rz;
-  const float cnx = fmaf(q0.x, tr.q.rx, tr.q.nx.x), cfx = fmaf(q0.x, tr.q.rx, tr.q.nx.y);
-  const float cny = fmaf(q0.y, tr.q.ry, tr.q.ny.x), cfy = fmaf(q0.y, tr.q.ry, tr.q.ny.y);
-  const float cnz = fmaf(q0.z, tr.q.rz, tr.q.nz.x), cfz = fmaf(q0.z, tr.q.rz, tr.q.nz.y);
-  // the planes met first: the low ones for a ray travelling up the axis, the high ones otherwise
-  const uint32_t nwx = pick_bits(tr.offx, q2.x, q1.x), fwx = pick_bits(tr.offx, q1.x, q2.x);
-  const uint32_t nwy = pick_bits(tr.offy, q2.y, q1.y), fwy = pick_bits(tr.offy, q1.y, q2.y);
-  const uint32_t nwz = pick_bits(tr.offz, q2.z, q1.z), fwz = pick_bits(tr.offz, q1.z, q2.z);
-  float tn0, tn1, tn2, tn3;
-  bool h0, h1, h2, h3;
-  wide_pair<0>(tr, nwx, nwy, nwz, fwx, fwy, fwz, ax, ay, az, cnx, cny, cnz, cfx, cfy, cfz, tminf, tn0, tn1, h0, h1);
-  wide_pair<1>(tr, nwx, nwy, nwz, fwx, fwy, fwz, ax, ay, az, cnx, cny, cnz, cfx, cfy, cfz, tminf, tn2, tn3, h2, h3);
-  // a node has at least two children; the boxes of absent ones are inverted, and their reference makes sure
-  h2 = h2 && refs.z != kRefDone;
-  h3 = h3 && refs.w != kRefDone;
+  const RayBox& q = tr.q;
+  const float tn0 = max3_raw(fmaf(NX.x, q.rx, q.nx.x), fmaf(NY.x, q.ry, q.ny.x), max_raw(fmaf(NZ.x, q.rz, q.nz.x), tminf));
+  const float tn1 = max3_raw(fmaf(NX.y, q.rx, q.nx.x), fmaf(NY.y, q.ry, q.ny.x), max_raw(fmaf(NZ.y, q.rz, q.nz.x), tminf));
+  const float tn2 = max3_raw(fmaf(NX.z, q.rx, q.nx.x), fmaf(NY.z, q.ry, q.ny.x), max_raw(fmaf(NZ.z, q.rz, q.nz.x), tminf));
+  const float tn3 = max3_raw(fmaf(NX.w, q.rx, q.nx.x), fmaf(NY.w, q.ry, q.ny.x), max_raw(fmaf(NZ.w, q.rz, q.nz.x), tminf));
+  const float tf0 = min3_raw(fmaf(FX.x, q.rx, q.nx.y), fmaf(FY.x, q.ry, q.ny.y), min_raw(fmaf(FZ.x, q.rz, q.nz.y), tr.tmaxf));
+  const float tf1 = min3_raw(fmaf(FX.y, q.rx, q.nx.y), fmaf(FY.y, q.ry, q.ny.y), min_raw(fmaf(FZ.y, q.rz, q.nz.y), tr.tmaxf));
+  const float tf2 = min3_raw(fmaf(FX.z, q.rx, q.nx.y), fmaf(FY.z, q.ry, q.ny.y), min_raw(fmaf(FZ.z, q.rz, q.nz.y), tr.tmaxf));
+  const float tf3 = min3_raw(fmaf(FX.w, q.rx, q.nx.y), fmaf(FY.w, q.ry, q.ny.y), min_raw(fmaf(FZ.w, q.rz, q.nz.y), tr.tmaxf));
+  bool h0 = tn0 <= tf0, h1 = tn1 <= tf1, h2 = tn2 <= tf2, h3 = tn3 <= tf3;
+  // (a node has at least two children; an absent child's box is inverted and infinite, so it is never hit:
+  // inf * r + c is +inf on its near side and -inf on its far side, or NaN on both, which the min/max drop, on an
+  // axis the ray does not move along -- never on all three)
   const float inf = __builtin_inff();
   const float t0 = h0 ? tn0 : inf, t1 = h1 ? tn1 : inf, t2 = h2 ? tn2 : inf, t3 = h3 ? tn3 : inf;
   const float m = min3_raw(t0, t1, min_raw(t2, t3));

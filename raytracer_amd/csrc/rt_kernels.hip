@@ -33,7 +33,10 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
     lcam[k] = src[k % 3];
   }
   if (kWide) {  // four-wide nodes are staged as they are, 80 bytes apart
-    for (uint32_t i = threadIdx.x; i < 4 * sc.n_nodes_lds; i += wg) lnodes[(kWideLdsStride / 16) * (i >> 2) + (i & 3u)] = gn[i];
+    for (uint32_t i = threadIdx.x; i < kWideStagedQuads * sc.n_nodes_lds; i += wg) {
+      const uint32_t node = i / kWideStagedQuads, quad = i - node * kWideStagedQuads;
+      lnodes[(kWideLdsStride / 16) * node + quad] = gn[kWideGlobalQuads * node + quad];
+    }
   } else {
     for (uint32_t i = threadIdx.x; i < sc.n_nodes_lds; i += wg) stage_node<kAllLds>(lnodes, i, gn[4 * i], gn[4 * i + 1], gn[4 * i + 2], gn[4 * i + 3]);
   }
@@ -609,7 +612,9 @@ size_t lds_node_bytes() { return kLdsNodeQuads * 16; }
 size_t lds_wide_node_bytes() { return kWideLdsStride; }
 size_t lds_fixed_bytes() { return CAM_DOUBLES * 8; }
 size_t tree_lds_bytes(const SceneDev& sc) {
-  if (sc.wide) return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * kWideLdsStride + (size_t)sc.lds_stack * kWorkgroup * 4;
+  if (sc.wide)
+    return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * kWideLdsStride + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
+           (size_t)sc.n_materials_lds * 32 + (size_t)sc.lds_stack * kWorkgroup * 4;
   return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * lds_node_bytes() + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
          (size_t)sc.n_materials_lds * 32 + (sc.stack_in_lds ? (size_t)sc.stack_cap * kWorkgroup * 4 : 0);
 }

@@ -66,6 +66,11 @@ __global__ __launch_bounds__(1024) void rate_kernel(float* out, float a, float b
       if (kOp == 44) { if (k & 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]" : "+v"(p[k]) : "v"(pa), "v"(pb)); else asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(x[k]) : "v"(p[k^1].x), "v"(p[k^1].y), "v"(b)); }
       if (kOp == 45) { if (k & 1) asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %3, %3, %1, %2" : "+v"(p[k].x), "+v"(p[k].y) : "v"(a), "v"(b)); else asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(x[k]) : "v"(p[k^1].x), "v"(p[k^1].y), "v"(b)); }
       if (kOp == 15) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pa));
+      if (kOp == 50) asm volatile("v_fma_mix_f32 %0, %1, %0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x[k]) : "v"(a), "v"(b));
+      if (kOp == 51) asm volatile("v_fma_mix_f32 %0, %1, %0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x[k]) : "v"(a), "v"(b));
+      if (kOp == 52) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x[k]) : "v"(a), "v"(b));
+      if (kOp == 53) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(x[k]) : "v"(a));
+      if (kOp == 54) asm volatile("v_perm_b32 %0, %0, %1, s20" : "+v"(x[k]) : "v"(a) : "s20");
     }
   }
   float s = 0;
@@ -127,6 +132,11 @@ int main() {
   run<34>("v_add_f32", out, cus);
   run<35>("v_mul_f32", out, cus);
   run<37>("v_mov_b64", out, cus);
+  run<50>("v_fma_mix_f32 lo half", out, cus);
+  run<51>("v_fma_mix_f32 hi half", out, cus);
+  run<52>("v_perm_b32", out, cus);
+  run<54>("v_perm_b32 sgpr selector", out, cus);
+  run<53>("v_cvt_f32_ubyte1", out, cus);
   run<40>("mix fma_f32 / max3", out, cus);
   run<41>("mix pk_fma / max3", out, cus);
   run<42>("mix fma_f32 / add_u32", out, cus);
