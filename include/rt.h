@@ -284,6 +284,14 @@ int rt_render_device_noalloc(const rt_scene* scene, const rt_config* cfg, uint64
  * mean active lanes and cycles to stderr (slower; results unchanged). */
 int rt_debug_set(const char* name, double value);
 
+/* Measurement harness, not a product path (no rt_render* entry point calls it): the same samples of the whole
+ * frame rendered by a wavefront pipeline -- one kernel per stage (generate, trace, shade, resolve) with ray queues
+ * in device memory, rays that go on packed with wave ballots -- so that its profile can be laid next to the
+ * persistent kernel's.  Same paths, hence the same frame up to the order of additions.  rgb_sum_dev is device
+ * memory and is added to; runs on the default stream and waits for it. */
+int rt_experiment_wavefront_device(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
+                                   double* rgb_sum_dev, rt_render_stats* stats);
+
 /* `write_colour` (src/camera.rs:85-95) for n pixels: out is n x 3 bytes. Host only. */
 int rt_quantise(const double* rgb_sum, size_t n_pixels, uint64_t samples_per_pixel, uint8_t* out);
 

@@ -320,6 +320,15 @@ class Camera:
                                                   C.c_uint32(spp_end), ptr(rect), C.c_void_p(rgb_sum_ptr), C.c_void_p(stream or 0), ptr(stats)))
         return {k: stats[k][0].item() for k in RENDER_STATS_DTYPE.names} if want_stats else None
 
+    def render_wavefront_device(self, bvh, rgb_sum_ptr, seed=0, spp_begin=0, spp_end=None):
+        """The measurement harness: the same samples through the wavefront pipeline (whole frame)."""
+        if spp_end is None:
+            spp_end = self.config.get("samples_per_pixel")
+        stats = np.zeros(1, dtype=RENDER_STATS_DTYPE)
+        check(_lib.lib().rt_experiment_wavefront_device(bvh._h, ptr(self.config.record()), C.c_uint64(seed), C.c_uint32(spp_begin),
+                                                        C.c_uint32(spp_end), C.c_void_p(rgb_sum_ptr), ptr(stats)))
+        return {k: stats[k][0].item() for k in RENDER_STATS_DTYPE.names}
+
     def partition(self, n_devices, partition=PARTITION_TILES, spp_begin=0, spp_end=None, tile=None):
         """The shares `render_multi` gives to n_devices devices: an array of SHARD_DTYPE records."""
         if spp_end is None:

@@ -113,6 +113,8 @@ std::atomic<bool> g_force_staged_sum{false};
 std::atomic<uint32_t> g_wide_lds_stack{8};
 // Test hook: scenes created while this is set are walked through the four-wide tree even if they fit in LDS two-wide.
 std::atomic<bool> g_force_wide{false};
+// Paths the wavefront harness keeps in flight (whole samples of the frame, at least one).
+std::atomic<uint64_t> g_wavefront_paths{32u << 20};
 
 // Partial sums of an allocating render call never exceed this; the sample range is cut into fewer chunks instead.
 constexpr uint64_t kWorkspaceLimit = 4ull << 30;
@@ -1212,6 +1214,58 @@ int rt_render_device_noalloc(const rt_scene* sc, const rt_config* cfg, uint64_t 
   });
 }
 
+int rt_experiment_wavefront_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
+                                   double* rgb_sum_dev, rt_render_stats* stats) {
+  return guarded("rt_experiment_wavefront_device", [&]() -> int {
+    if (!sc || !rgb_sum_dev) return fail(RT_ERR_INVALID, "rt_experiment_wavefront_device: null argument");
+    CameraDev cam;
+    int rc = make_camera_dev(cfg, &cam, "rt_experiment_wavefront_device");
+    if (rc) return rc;
+    if (spp_end < spp_begin) return fail(RT_ERR_INVALID, "rt_experiment_wavefront_device: spp_end < spp_begin");
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (spp_end == spp_begin || cam.max_depth == 0) return RT_OK;
+    const Replica& rp = *sc->reps[0];
+    DeviceGuard g(rp.device);
+    RT_HIP(g.status);
+    const uint64_t n_pixels = (uint64_t)cam.width * cam.height;
+    if (n_pixels > (1u << 26)) return fail(RT_ERR_LIMIT, "rt_experiment_wavefront_device: at most 2^26 pixels");
+    // paths in flight: as many whole samples of the frame as fit in the budget (32 million by default), at least one
+    const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(spp_end - spp_begin, g_wavefront_paths.load() / n_pixels));
+    if (batch * n_pixels > 0xfff00000ull) return fail(RT_ERR_LIMIT, "rt_experiment_wavefront_device: too many paths in flight");
+    const uint32_t capacity = (uint32_t)(batch * n_pixels);
+    SceneDev dev = rp.dev;
+    DevBuf work, gstack;
+    RT_HIP(work.alloc(wavefront_workspace_bytes(capacity)));
+    if (dev.wide && dev.stack_cap > dev.lds_stack) {
+      dev.gstack_stride = (uint32_t)rp.num_cus * kWorkgroup;
+      RT_HIP(gstack.alloc((size_t)dev.gstack_stride * (dev.stack_cap - dev.lds_stack) * 4));
+      dev.gstack = gstack.as<uint32_t>();
+    }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    RT_HIP(hipEventCreate(&ev0));
+    RT_HIP(hipEventCreate(&ev1));
+    RT_HIP(hipEventRecord(ev0, nullptr));
+    uint64_t rays = 0;
+    uint32_t launches = 0;
+    hipError_t e = wavefront_render(dev, cam, seed, spp_begin, spp_end, rgb_sum_dev, work.p, capacity, rp.num_cus, nullptr, &rays, &launches);
+    hipError_t e2 = hipEventRecord(ev1, nullptr);
+    if (e == hipSuccess) e = e2;
+    if (e == hipSuccess) e = hipEventSynchronize(ev1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    RT_HIP(e);
+    if (stats) {
+      stats->rays = rays;
+      stats->samples = n_pixels * (spp_end - spp_begin);
+      stats->kernel_ms = ms;
+      stats->launches = launches;
+    }
+    return RT_OK;
+  });
+}
+
 int rt_render(const rt_scene* sc, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile,
               double* rgb_sum, rt_render_stats* stats) {
   return guarded("rt_render", [&]() -> int {
@@ -1337,6 +1391,11 @@ int rt_debug_set(const char* name, double value) {
     }
     if (key == "force_global_stack") {
       g_force_global_stack.store(value != 0.0);
+      return RT_OK;
+    }
+    if (key == "wavefront_paths") {
+      if (!(value >= 1.0 && value <= 4e9)) return fail(RT_ERR_INVALID, "rt_debug_set: wavefront_paths must be in 1 .. 4e9");
+      g_wavefront_paths.store((uint64_t)value);
       return RT_OK;
     }
     if (key == "force_wide") {

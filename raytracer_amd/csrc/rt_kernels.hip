@@ -7,64 +7,6 @@
 
 namespace rta {
 
-// LDS image of a workgroup:
-//   [camera constants][top-of-tree nodes][sphere slots][slot shading data][materials][per-lane stacks]
-struct LdsImage {
-  TreeView tv;
-  CamLds cam;
-  lds_u32* stack_base;
-};
-
-template <bool kAllLds, bool kWide = false>
-__device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const CameraDev* cam, float4* smem, uint32_t wg) {
-  lds_double* lcam = (lds_double*)smem;
-  lds_float4* lnodes = (lds_float4*)(lcam + CAM_DOUBLES);
-  lds_double2* lsph = (lds_double2*)(lnodes + (kWide ? kWideLdsStride / 16 : kLdsNodeQuads) * sc.n_nodes_lds);
-  lds_double2* laux = lsph + 2 * sc.n_spheres_lds;
-  lds_double2* lmat = laux + sc.n_aux_lds;
-  lds_u32* stack_base = (lds_u32*)(lmat + 2 * sc.n_materials_lds);
-  const f32x4* gn = reinterpret_cast<const f32x4*>(sc.nodes);
-  const f64x2* gs = reinterpret_cast<const f64x2*>(sc.spheres);
-  const f64x2* ga = reinterpret_cast<const f64x2*>(sc.aux);
-  const f64x2* gm = reinterpret_cast<const f64x2*>(sc.materials);
-  if (cam && threadIdx.x < CAM_DOUBLES) {
-    const uint32_t k = threadIdx.x;
-    const double* src = k < 3 ? cam->center : k < 6 ? cam->pixel00 : k < 9 ? cam->du : k < 12 ? cam->dv : k < 15 ? cam->disk_u : cam->disk_v;
-    lcam[k] = src[k % 3];
-  }
-  if (kWide) {  // four-wide nodes are staged as they are, 80 bytes apart
-    for (uint32_t i = threadIdx.x; i < kWideStagedQuads * sc.n_nodes_lds; i += wg) {
-      const uint32_t node = i / kWideStagedQuads, quad = i - node * kWideStagedQuads;
-      lnodes[(kWideLdsStride / 16) * node + quad] = gn[kWideGlobalQuads * node + quad];
-    }
-  } else {
-    for (uint32_t i = threadIdx.x; i < sc.n_nodes_lds; i += wg) stage_node<kAllLds>(lnodes, i, gn[4 * i], gn[4 * i + 1], gn[4 * i + 2], gn[4 * i + 3]);
-  }
-  for (uint32_t i = threadIdx.x; i < 2 * sc.n_spheres_lds; i += wg) lsph[i] = gs[i];
-  for (uint32_t i = threadIdx.x; i < sc.n_aux_lds; i += wg) laux[i] = ga[i];
-  for (uint32_t i = threadIdx.x; i < 2 * sc.n_materials_lds; i += wg) lmat[i] = gm[i];
-  __syncthreads();
-  LdsImage im;
-  im.tv.gnodes = sc.nodes;
-  im.tv.lnodes = lnodes;
-  im.tv.gsph = sc.spheres;
-  im.tv.lsph = lsph;
-  im.tv.gaux = sc.aux;
-  im.tv.laux = laux;
-  im.tv.gmat = sc.materials;
-  im.tv.lmat = lmat;
-  im.tv.n_lds = sc.n_nodes_lds;
-  im.tv.n_sph_lds = sc.n_spheres_lds;
-  im.tv.n_aux_lds = sc.n_aux_lds;
-  im.tv.n_mat_lds = sc.n_materials_lds;
-  im.tv.root = sc.root;
-  im.tv.bound = sc.bound;
-  im.tv.single_leaves = sc.single_leaves != 0u;
-  im.cam.p = lcam;
-  im.stack_base = stack_base;
-  return im;
-}
-
 // ------------------------------------------------------------ trace batch ----
 template <bool kAllLds, bool kGStack, bool kWide = false>
 __global__ __launch_bounds__(kWorkgroup) void trace_batch_kernel(SceneDev sc, const double* __restrict__ org, const double* __restrict__ dir,
