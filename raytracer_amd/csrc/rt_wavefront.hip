@@ -6,7 +6,7 @@
 //   generate   camera rays of a batch of paths (all pixels x a few samples)        -> queue A
 //   trace      closest hit of every queued ray (one ray per lane, to completion)     -> hit records
 //   shade      sky for rays that left the scene, else hit record + scatter; rays that go on are packed into the
-//              other queue (ballot + prefix count per wave, one atomic per wave)     -> queue B, per-path results
+//              other queue (ballot + prefix count per wave, one atomic per workgroup) -> queue B, per-path results
 //   resolve    adds each pixel's path results in sample order to the frame
 //
 // Queues are arrays of one component each (coalesced): origin, direction, throughput (nine doubles), path id.
