@@ -294,23 +294,26 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   const bool wide = (!fits || g_force_wide.load()) && n_dev_nodes > 0;
   uint32_t lds_stack = 0;
   size_t n_final_nodes = n_dev_nodes;
+  uint32_t wide_stack_entries = 0;
+  float wide_bound = 0.0f;
+  void* d_wide = nullptr;
   if (wide) {
-    if (wide_cache->nodes.empty()) {
-      if (on_device) {
-        std::vector<DevNode> host_nodes(n_dev_nodes);
-        RT_HIP(hipMemcpy(host_nodes.data(), rp.d_nodes, node_bytes, hipMemcpyDeviceToHost));
-        *wide_cache = collapse_wide(host_nodes.data(), n_dev_nodes);
-      } else {
-        *wide_cache = collapse_wide(flat.nodes.data(), n_dev_nodes);
-      }
-    }
-    if (on_device) {
+    if (on_device) {  // the device builder's nodes are collapsed where they are
+      uint32_t n_wide = 0, levels = 0;
+      hipError_t e = device_collapse_wide(rp.d_nodes, (uint32_t)n_dev_nodes, &d_wide, &n_wide, &levels, nullptr);
       (void)hipFree(rp.d_nodes);
-      rp.d_nodes = nullptr;
+      rp.d_nodes = d_wide;  // owned by the replica from here on, also if the call failed half-way
+      RT_HIP(e);
+      n_final_nodes = n_wide;
+      wide_stack_entries = 3 * levels + 1;  // at most three children set aside per level
+      wide_bound = tree.bound;
+    } else {
+      if (wide_cache->nodes.empty()) *wide_cache = collapse_wide(flat.nodes.data(), n_dev_nodes);
+      n_final_nodes = wide_cache->nodes.size();
+      wide_stack_entries = wide_cache->stack_entries;
+      wide_bound = std::fmax(wide_cache->bound, flat.bound);
     }
-    const WideBvh& wb = *wide_cache;
-    n_final_nodes = wb.nodes.size();
-    lds_stack = g_force_global_stack.load() ? 0u : std::min<uint32_t>(wb.stack_entries, g_wide_lds_stack.load());
+    lds_stack = g_force_global_stack.load() ? 0u : std::min<uint32_t>(wide_stack_entries, g_wide_lds_stack.load());
     const size_t wide_room = kLdsPerCu - reserve - (size_t)lds_stack * kWorkgroup * 4;
     size_t wide_left = wide_room;
     n_nodes_lds = (uint32_t)std::min(n_final_nodes, wide_left / lds_wide_node_bytes());
@@ -325,8 +328,10 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
         if (used_mat_bytes <= wide_left) n_mat_lds = (uint32_t)n_used;
       }
     }
-    RT_HIP(hipMalloc(&rp.d_nodes, n_final_nodes * sizeof(WideNode)));
-    RT_HIP(hipMemcpy(rp.d_nodes, wb.nodes.data(), n_final_nodes * sizeof(WideNode), hipMemcpyHostToDevice));
+    if (!on_device) {
+      RT_HIP(hipMalloc(&rp.d_nodes, n_final_nodes * sizeof(WideNode)));
+      RT_HIP(hipMemcpy(rp.d_nodes, wide_cache->nodes.data(), n_final_nodes * sizeof(WideNode), hipMemcpyHostToDevice));
+    }
   } else if (!on_device) {
     RT_HIP(hipMalloc(&rp.d_nodes, node_bytes ? node_bytes : 64));
     if (node_bytes) RT_HIP(hipMemcpy(rp.d_nodes, flat.nodes.data(), node_bytes, hipMemcpyHostToDevice));
@@ -352,12 +357,12 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   dev.n_spheres_lds = n_sph_lds;
   dev.n_aux_lds = n_aux_lds;
   dev.n_materials_lds = n_mat_lds;
-  dev.stack_cap = wide ? wide_cache->stack_entries : depth;
+  dev.stack_cap = wide ? wide_stack_entries : depth;
   dev.stack_in_lds = wide ? 1u : (stack_in_lds ? 1u : 0u);
   dev.wide = wide ? 1u : 0u;
   dev.lds_stack = lds_stack;
   dev.root = wide ? 0u : (on_device ? tree.root : flat.root);
-  dev.bound = wide ? std::fmax(wide_cache->bound, on_device ? tree.bound : flat.bound) : (on_device ? tree.bound : flat.bound);
+  dev.bound = wide ? wide_bound : (on_device ? tree.bound : flat.bound);
   bool single = true;  // the device builder makes one-sphere leaves only
   if (!on_device) {
     auto one = [](uint32_t ref) { return !(ref & kRefLeaf) || ref == kRefNone || ((ref >> 24) & 0x7fu) == 1u; };

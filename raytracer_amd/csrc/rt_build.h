@@ -27,4 +27,10 @@ struct DeviceTree {
 hipError_t device_build_lbvh(const rt_sphere* spheres, size_t n, const uint8_t* material_type, size_t n_materials, DeviceTree* out,
                              hipStream_t stream);
 
+// The four-wide tree (WideNode records, bvh_builder.h) collapsed on the device from n_two_wide two-wide nodes in
+// device memory (root = node 0), by the algorithm of collapse_wide on the host, breadth-first.  *d_wide_out is
+// allocated with hipMalloc and owned by the caller.  levels: levels of wide nodes.
+hipError_t device_collapse_wide(const void* d_two_wide_nodes, uint32_t n_two_wide, void** d_wide_out, uint32_t* n_wide_out, uint32_t* levels_out,
+                                hipStream_t stream);
+
 }  // namespace rta

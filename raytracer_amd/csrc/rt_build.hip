@@ -5,6 +5,7 @@
 // rendering; the tree differs from the reference's binned-SAH tree, the closest
 // hits do not (they depend on the spheres only).
 #include <cstring>
+#include <utility>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -307,6 +308,132 @@ struct Scratch {
   } while (0)
 
 }  // namespace
+
+// ------------------------------------------------- four-wide collapse ----
+// The four-wide tree of bvh_builder.h (WideNode) from two-wide device nodes, level by level: a wide node takes
+// the two children of its two-wide root and then, twice, replaces the inner child of largest surface area by that
+// child's own children.  Per level: count each wide node's inner children, exclusive scan, emit -- so the
+// numbering is breadth-first and the same in every run, children in child order (what the host collapse makes).
+struct WideChild {
+  float lo[3], hi[3];
+  uint32_t ref;
+};
+__device__ __forceinline__ void two_wide_children(const float4* __restrict__ nodes, uint32_t b, WideChild out[2]) {
+  const float4 x = nodes[4 * (size_t)b], y = nodes[4 * (size_t)b + 1], z = nodes[4 * (size_t)b + 2], r = nodes[4 * (size_t)b + 3];
+  out[0] = WideChild{{x.x, y.x, z.x}, {x.y, y.y, z.y}, __float_as_uint(r.x)};
+  out[1] = WideChild{{x.z, y.z, z.z}, {x.w, y.w, z.w}, __float_as_uint(r.y)};
+}
+__device__ __forceinline__ double half_area(const WideChild& c) {
+  const double dx = (double)c.hi[0] - c.lo[0], dy = (double)c.hi[1] - c.lo[1], dz = (double)c.hi[2] - c.lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+__device__ __forceinline__ int gather_wide_children(const float4* __restrict__ nodes, uint32_t root, WideChild ch[4]) {
+  int n = 2;
+  two_wide_children(nodes, root, ch);
+  while (n < 4) {
+    int pick = -1;
+    double best = -1.0;
+    for (int k = 0; k < n; ++k)
+      if (!(ch[k].ref & 0x80000000u) && half_area(ch[k]) > best) {
+        best = half_area(ch[k]);
+        pick = k;
+      }
+    if (pick < 0) break;
+    WideChild two[2];
+    two_wide_children(nodes, ch[pick].ref, two);
+    ch[pick] = two[0];
+    ch[n++] = two[1];
+  }
+  return n;
+}
+__global__ __launch_bounds__(kThreads) void wide_count_kernel(const float4* __restrict__ nodes, const uint32_t* __restrict__ roots, uint32_t count,
+                                                            uint32_t* __restrict__ n_inner_children) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= count) return;
+  WideChild ch[4];
+  const int n = gather_wide_children(nodes, roots[i], ch);
+  uint32_t inner = 0;
+  for (int k = 0; k < n; ++k) inner += (ch[k].ref & 0x80000000u) ? 0u : 1u;
+  n_inner_children[i] = inner;
+}
+__global__ __launch_bounds__(kThreads) void wide_emit_kernel(const float4* __restrict__ nodes, const uint32_t* __restrict__ roots, uint32_t count,
+                                                           const uint32_t* __restrict__ child_offset, uint32_t level_base, uint32_t next_base,
+                                                           uint32_t* __restrict__ next_roots, float4* __restrict__ wide) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= count) return;
+  WideChild ch[4];
+  const int n = gather_wide_children(nodes, roots[i], ch);
+  const float inf = __builtin_inff();
+  float4 q[8];
+  for (int a = 0; a < 3; ++a) {
+    float lo[4], hi[4];
+    for (int k = 0; k < 4; ++k) {
+      lo[k] = k < n ? ch[k].lo[a] : inf;   // a child that does not exist: inverted, infinite box
+      hi[k] = k < n ? ch[k].hi[a] : -inf;
+    }
+    q[2 * a] = make_float4(lo[0], lo[1], lo[2], lo[3]);
+    q[2 * a + 1] = make_float4(hi[0], hi[1], hi[2], hi[3]);
+  }
+  uint32_t refs[4], at = child_offset[i];
+  for (int k = 0; k < 4; ++k) {
+    if (k >= n) {
+      refs[k] = 0xffffffffu;
+    } else if (ch[k].ref & 0x80000000u) {
+      refs[k] = ch[k].ref;
+    } else {
+      next_roots[at] = ch[k].ref;
+      refs[k] = next_base + at;
+      ++at;
+    }
+  }
+  q[6] = make_float4(__uint_as_float(refs[0]), __uint_as_float(refs[1]), __uint_as_float(refs[2]), __uint_as_float(refs[3]));
+  q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float4* dst = wide + 8 * (size_t)(level_base + i);
+  for (int k = 0; k < 8; ++k) dst[k] = q[k];
+}
+
+hipError_t device_collapse_wide(const void* d_two_wide_nodes, uint32_t n_two_wide, void** d_wide_out, uint32_t* n_wide_out, uint32_t* levels_out,
+                                hipStream_t stream) {
+  *d_wide_out = nullptr;
+  const float4* nodes = static_cast<const float4*>(d_two_wide_nodes);
+  Scratch roots_a, roots_b, counts, offsets, scan_tmp, all;
+  RTB(roots_a.alloc((size_t)n_two_wide * 4));
+  RTB(roots_b.alloc((size_t)n_two_wide * 4));
+  RTB(counts.alloc((size_t)n_two_wide * 4 + 4));
+  RTB(offsets.alloc((size_t)n_two_wide * 4 + 4));
+  RTB(all.alloc((size_t)n_two_wide * 128));  // at most one wide node per two-wide node; trimmed below
+  size_t tmp_bytes = 0;
+  RTB(rocprim::exclusive_scan(nullptr, tmp_bytes, counts.as<uint32_t>(), offsets.as<uint32_t>(), 0u, (size_t)n_two_wide + 1, rocprim::plus<uint32_t>(), stream));
+  RTB(scan_tmp.alloc(tmp_bytes));
+  const uint32_t zero = 0;
+  RTB(hipMemcpyAsync(roots_a.p, &zero, 4, hipMemcpyHostToDevice, stream));  // the root of the two-wide tree is node 0
+  uint32_t count = 1, base = 0, levels = 0;
+  uint32_t* cur = roots_a.as<uint32_t>();
+  uint32_t* next = roots_b.as<uint32_t>();
+  while (count) {
+    const unsigned blocks = (count + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(wide_count_kernel, dim3(blocks), dim3(kThreads), 0, stream, nodes, cur, count, counts.as<uint32_t>());
+    RTB(hipMemsetAsync(counts.as<uint32_t>() + count, 0, 4, stream));  // one entry past the end: its offset is the level's total
+    RTB(rocprim::exclusive_scan(scan_tmp.p, tmp_bytes, counts.as<uint32_t>(), offsets.as<uint32_t>(), 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), stream));
+    hipLaunchKernelGGL(wide_emit_kernel, dim3(blocks), dim3(kThreads), 0, stream, nodes, cur, count, offsets.as<uint32_t>(), base, base + count, next,
+                       all.as<float4>());
+    RTB(hipGetLastError());
+    uint32_t next_count = 0;
+    RTB(hipMemcpyAsync(&next_count, offsets.as<uint32_t>() + count, 4, hipMemcpyDeviceToHost, stream));
+    RTB(hipStreamSynchronize(stream));
+    base += count;
+    count = next_count;
+    std::swap(cur, next);
+    ++levels;
+    if (base + (size_t)count > n_two_wide) return hipErrorUnknown;  // cannot happen for a tree; never write past the buffers
+  }
+  RTB(hipMalloc(d_wide_out, (size_t)base * 128));
+  RTB(hipMemcpyAsync(*d_wide_out, all.p, (size_t)base * 128, hipMemcpyDeviceToDevice, stream));
+  RTB(hipStreamSynchronize(stream));
+  *n_wide_out = base;
+  *levels_out = levels;
+  return hipSuccess;
+}
 
 hipError_t device_build_lbvh(const rt_sphere* h_spheres, size_t n_, const uint8_t* h_material_type, size_t n_materials, DeviceTree* out,
                              hipStream_t stream) {

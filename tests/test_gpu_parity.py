@@ -522,6 +522,16 @@ def test_device_built_tree_large_and_degenerate():
     got = world.trace_batch(org, d)
     prim, t = _brute_force_hits(spheres, org, d)
     assert np.array_equal(got["prim"], prim) and (np.abs(got["t"][prim >= 0] - t[prim >= 0]) <= 1e-9 * t[prim >= 0]).all()
+    # the four-wide tree collapsed on the device from the linear BVH against the one collapsed on the host from the
+    # reference's tree: two different trees over the same spheres must report the same closest hits
+    sah = rt.BVH(spheres, materials)
+    org2, d2 = _secondary_rays(spheres[1:], rng, 1 << 15)
+    org3, d3_ = rt.config_field(100000, 256, 4, 50).camera().primary_rays(
+        np.stack([rng.integers(0, 256, 1 << 15), rng.integers(0, 144, 1 << 15), rng.integers(0, 4, 1 << 15)], axis=1), seed=3)
+    for o, dd in ((org2, d2), (org3, d3_)):
+        ties, rel_t, dn = compare_hits(world.trace_batch(o, dd), sah.trace_batch(o, dd))
+        assert ties <= 4 and rel_t <= 1e-12
+    sah.close()
     world.close()
     mat = np.zeros(1, dtype=rt.MATERIAL_DTYPE)
     mat["albedo"] = (0.5, 0.5, 0.5)
