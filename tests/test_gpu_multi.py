@@ -169,3 +169,34 @@ def test_concurrent_multi_calls_serialise(triple, single):
             assert np.array_equal(out[k], want)
         else:
             assert np.abs(out[k] - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def test_device_list_is_checked(rtiow):
+    n = rt.device_count()
+    with pytest.raises(rt.RtError) as e:
+        rt.BVH(*rtiow, devices=[n])
+    assert e.value.code == 1 and "does not exist" in str(e.value)
+    with pytest.raises(rt.RtError) as e:
+        rt.BVH(*rtiow, devices=[-1])
+    assert e.value.code == 1
+    with pytest.raises(rt.RtError) as e:
+        rt.BVH(*rtiow, devices=[0] * 17)
+    assert e.value.code == 4
+    with pytest.raises(rt.RtError):
+        rt.BVH(*rtiow, devices=[])
+
+
+def test_multi_scene_through_the_four_wide_walk_and_device_builder():
+    # a scene that does not fit in LDS, copies built on the device: tiles still bit-identical, samples to rounding
+    spheres, materials = rt.scene_field(3, 20000, 1.0 / 3.0, 1.0 / 3.0)
+    one = rt.BVH(spheres, materials, builder=rt.BUILD_DEVICE_LBVH)
+    two = rt.BVH(spheres, materials, builder=rt.BUILD_DEVICE_LBVH, devices=[0, 0])
+    assert two.info()["n_devices"] == 2 and two.info()["builder"] == rt.BUILD_DEVICE_LBVH
+    cam = rt.config_field(20000, 120, 20, 50).camera()
+    want, st = cam.render_sum(one, seed=3)
+    got, st2 = cam.render_multi(two, seed=3, partition=rt.PARTITION_TILES)
+    assert np.array_equal(got, want) and st2["rays"] == st["rays"]
+    got, st2 = cam.render_multi(two, seed=3, partition=rt.PARTITION_SAMPLES)
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max() and st2["rays"] == st["rays"]
+    one.close()
+    two.close()
