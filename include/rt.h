@@ -113,9 +113,9 @@ typedef struct rt_render_stats {
 typedef struct rt_scene_info {
   uint64_t n_spheres;
   uint64_t n_nodes;         /* nodes of the host tree (splits + leaves) */
-  uint64_t n_device_nodes;  /* 64-byte device nodes (one per split) */
+  uint64_t n_device_nodes;  /* device nodes: 64-byte two-wide nodes (one per split) for a scene that fits in LDS, else 128-byte four-wide nodes */
   uint32_t depth;           /* levels in the BVH (a single leaf has depth 1) */
-  uint32_t n_nodes_in_lds;  /* nodes of the top of the tree staged in LDS by the kernels */
+  uint32_t n_nodes_in_lds;  /* device nodes of the top of the tree staged in LDS by the kernels */
   uint32_t spheres_in_lds;  /* bit 0: sphere records staged in LDS too; bit 1: their shading data; bit 2: the materials */
   uint32_t device;          /* HIP device ordinal the scene lives on */
   uint64_t device_bytes;    /* HBM held by the scene */
