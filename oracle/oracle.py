@@ -93,6 +93,15 @@ def philox4x32_10(key, ctr):
     return out
 
 
+def philox4x32(key, ctr, rounds):
+    """Philox4x32 with the given number of rounds (10: the published default; 7: what the render loop draws from)."""
+    key = np.asarray(key, dtype=np.uint32)
+    ctr = np.asarray(ctr, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32(_p(key), _p(ctr), _p(out), C.c_int(rounds))
+    return out
+
+
 def philox_pair(seed, pixel, sample, slot, domain):
     u = np.zeros(2)
     lib().orc_philox_pair(C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_uint32(slot), C.c_uint32(domain), _p(u))

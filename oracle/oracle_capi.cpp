@@ -16,6 +16,7 @@ static inline void st(double* p, V3 v) {
 extern "C" {
 
 void orc_philox4x32_10(const uint32_t* key, const uint32_t* ctr, uint32_t* out) { philox4x32_10(key, ctr, out); }
+void orc_philox4x32(const uint32_t* key, const uint32_t* ctr, uint32_t* out, int rounds) { philox4x32(key, ctr, out, rounds); }
 
 void orc_philox_pair(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t slot, uint32_t domain, double* u) {
   philox_pair(seed, pixel, sample, slot, domain, u);

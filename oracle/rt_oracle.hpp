@@ -388,13 +388,16 @@ static inline bool bvh_hit(const BVH& bvh, const Ray& r, Interval ray_t, HitReco
 }
 
 // --------------------------------------------------------------- Philox ----
-// Philox4x32-10 (Salmon et al., SC'11).  The reference draws from an
+// Philox4x32 (Salmon et al., SC'11).  The reference draws from an
 // unseeded thread-local ChaCha12 (src/vector.rs:10-12, src/camera.rs:115-116,
 // src/material.rs:58) and is not reproducible; a counter-based generator
-// with the same output distributions takes its place.
-static inline void philox4x32_10(const uint32_t key[2], const uint32_t ctr[4], uint32_t out[4]) {
+// with the same output distributions takes its place.  Ten rounds are the
+// published default (scene generation, the sequential stream of the
+// rejection samplers); the draws of the render loop in direct mode use seven,
+// the fewest the authors found to pass BigCrush, as the GPU path does.
+static inline void philox4x32(const uint32_t key[2], const uint32_t ctr[4], uint32_t out[4], int rounds) {
   uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < rounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
     uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
@@ -404,6 +407,8 @@ static inline void philox4x32_10(const uint32_t key[2], const uint32_t ctr[4], u
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+static inline void philox4x32_10(const uint32_t key[2], const uint32_t ctr[4], uint32_t out[4]) { philox4x32(key, ctr, out, 10); }
+static const int RENDER_ROUNDS = 7;
 // rand 0.8.5 Standard for f64: 53 random bits scaled by 2^-53, in [0,1).
 static inline double u64_to_unit(uint32_t lo, uint32_t hi) {
   uint64_t v = ((uint64_t)hi << 32) | lo;
@@ -419,6 +424,23 @@ static inline void philox_pair(uint64_t seed, uint32_t pixel, uint32_t sample, u
   philox4x32_10(key, ctr, o);
   u[0] = u64_to_unit(o[0], o[1]);
   u[1] = u64_to_unit(o[2], o[3]);
+}
+// The render loop's draws in direct mode: two uniforms of 53 bits per scatter event ...
+static inline void render_pair(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t slot, uint32_t domain, double u[2]) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t ctr[4] = {pixel, sample, slot, domain};
+  uint32_t o[4];
+  philox4x32(key, ctr, o, RENDER_ROUNDS);
+  u[0] = u64_to_unit(o[0], o[1]);
+  u[1] = u64_to_unit(o[2], o[3]);
+}
+// ... and four of 32 bits (word * 2^-32) per camera ray: the position in the pixel and the point on the lens.
+static inline void render_quad(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t slot, uint32_t domain, double u[4]) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t ctr[4] = {pixel, sample, slot, domain};
+  uint32_t o[4];
+  philox4x32(key, ctr, o, RENDER_ROUNDS);
+  for (int k = 0; k < 4; ++k) u[k] = (double)o[k] * (1.0 / 4294967296.0);
 }
 
 // ------------------------------------------------ vector.rs helpers --------
@@ -592,9 +614,9 @@ static inline Camera config_camera(const Config& c) {
 // src/camera.rs:114-136
 static inline Ray get_ray(const Camera& cam, uint32_t i, uint32_t j, PathRng& g) {
   V3 pixel_center = cam.pixel00_loc + ((double)i * cam.pixel_delta_u) + ((double)j * cam.pixel_delta_v);
-  double u[2];
+  double u[4] = {0.0, 0.0, 0.0, 0.0};
   if (g.mode == SAMPLER_DIRECT) {
-    philox_pair(g.seed, g.pixel, g.sample, 0, DOM_CAMERA, u);
+    render_quad(g.seed, g.pixel, g.sample, 0, DOM_CAMERA, u);  // one block per camera ray: pixel position, lens point
   } else {
     u[0] = g.stream_next();
     u[1] = g.stream_next();
@@ -606,14 +628,7 @@ static inline Ray get_ray(const Camera& cam, uint32_t i, uint32_t j, PathRng& g)
   if (cam.config.defocus_angle <= 0.0) {
     ray_origin = cam.center;
   } else {
-    V3 p;
-    if (g.mode == SAMPLER_DIRECT) {
-      double d[2];
-      philox_pair(g.seed, g.pixel, g.sample, 1, DOM_CAMERA, d);
-      p = disk_from_uniforms(d[0], d[1]);
-    } else {
-      p = random_disk_rejection(g);
-    }
+    V3 p = g.mode == SAMPLER_DIRECT ? disk_from_uniforms(u[2], u[3]) : random_disk_rejection(g);
     ray_origin = cam.center + p.x * cam.defocus_disk_u + p.y * cam.defocus_disk_v;
   }
   V3 ray_direction = pixel_sample - ray_origin;
@@ -629,7 +644,7 @@ static inline ScatterDraw draw_for_bounce(PathRng& g, const Material& m, const H
   ScatterDraw d{v3(0, 0, 0), 0.0};
   if (g.mode == SAMPLER_DIRECT) {
     double u[2];
-    philox_pair(g.seed, g.pixel, g.sample, bounce, DOM_SCATTER, u);
+    render_pair(g.seed, g.pixel, g.sample, bounce, DOM_SCATTER, u);
     d.unit = unit_from_uniforms(u[0], u[1]);
     d.coin = u[0];
   } else {

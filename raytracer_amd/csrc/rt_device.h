@@ -10,13 +10,16 @@
 namespace rta {
 
 // --------------------------------------------------------------- Philox ----
-// Philox4x32-10.  Counter = (pixel, sample, slot, domain), key = seed.
+// Philox4x32 (Salmon et al., SC'11).  Counter = (pixel, sample, slot, domain), key = seed.  The draws of the
+// render loop use seven rounds, the fewest its authors found to pass BigCrush; ten rounds are the published
+// default, which the host keeps for the scene generator.
 enum : uint32_t { DOM_CAMERA = 0, DOM_SCATTER = 1 };
+constexpr int kRenderRounds = 7;
 
-__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t out[4]) {
+__device__ __forceinline__ void philox4x32_render(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                  uint32_t out[4]) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < kRenderRounds; ++r) {
     // one 32x32->64 multiply per word pair (v_mad_u64_u32) instead of separate high and low products
     const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
@@ -37,12 +40,22 @@ __device__ __forceinline__ double unit_from_bits(uint32_t lo, uint32_t hi) {
   unsigned long long v = ((unsigned long long)hi << 32) | lo;
   return (double)(v >> 11) * (1.0 / 9007199254740992.0);
 }
+// Two uniforms of 53 bits from one block: what a scatter event draws.
 __device__ __forceinline__ void philox_pair(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t slot, uint32_t domain,
                                             double& u0, double& u1) {
   uint32_t o[4];
-  philox4x32_10(k0, k1, pixel, sample, slot, domain, o);
+  philox4x32_render(k0, k1, pixel, sample, slot, domain, o);
   u0 = unit_from_bits(o[0], o[1]);
   u1 = unit_from_bits(o[2], o[3]);
+}
+// Four uniforms of 32 bits (word * 2^-32, in [0,1)) from one block: what a camera ray draws -- the position in
+// the pixel and the point on the lens, neither of which can tell 2^-32 from 2^-53.
+__device__ __forceinline__ void philox_quad(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t slot, uint32_t domain,
+                                            double u[4]) {
+  uint32_t o[4];
+  philox4x32_render(k0, k1, pixel, sample, slot, domain, o);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) u[k] = (double)o[k] * (1.0 / 4294967296.0);
 }
 
 // ---------------------------------------------------------------- maths ----
@@ -181,15 +194,14 @@ __device__ __forceinline__ void camera_ray(const Cam& cam, uint32_t width, bool 
   const uint32_t pixel = j * width + i;
   const D3 du = cam.get(CAM_DU), dv = cam.get(CAM_DV);
   D3 pixel_center = cam.get(CAM_PIXEL00) + ((double)i * du) + ((double)j * dv);
-  double u0, u1;
-  philox_pair(k0, k1, pixel, s, 0, DOM_CAMERA, u0, u1);
-  double px = -0.5 + u0, py = -0.5 + u1;
+  double u[4];  // one block per camera ray: (0, 1) the position in the pixel, (2, 3) the point on the lens
+  philox_quad(k0, k1, pixel, s, 0, DOM_CAMERA, u);
+  double px = -0.5 + u[0], py = -0.5 + u[1];
   D3 pixel_sample = pixel_center + ((px * du) + (py * dv));
   org = cam.get(CAM_CENTER);
   if (defocus) {
-    philox_pair(k0, k1, pixel, s, 1, DOM_CAMERA, u0, u1);
     double dx, dy;
-    disk_from_uniforms(u0, u1, dx, dy);
+    disk_from_uniforms(u[2], u[3], dx, dy);
     org = org + dx * cam.get(CAM_DISK_U) + dy * cam.get(CAM_DISK_V);
   }
   dir = normalize(pixel_sample - org);

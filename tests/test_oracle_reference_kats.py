@@ -1,6 +1,6 @@
 """Pins the CPU oracle against every known-answer test the reference holds
 (src/aabb.rs:89-194, src/sphere.rs:83-117; constants in golden/reference_kats.json)
-and against the published Philox4x32-10 vectors."""
+and against the published Philox4x32 vectors (10 and 7 rounds)."""
 import json
 import math
 import os
@@ -84,3 +84,13 @@ def test_philox_known_answers(oracle):
     for ctr, key, want in kats:
         got = oracle.philox4x32_10(key, ctr)
         assert [int(x) for x in got] == want
+        assert [int(x) for x in oracle.philox4x32(key, ctr, 10)] == want
+    # The same file's vectors for 7 rounds, which the render loop draws from.
+    kats7 = [
+        ([0, 0, 0, 0], [0, 0], [0x5F6FB709, 0x0D893F64, 0x4F121F81, 0x4F730A48]),
+        ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x5207DDC2, 0x45165E59, 0x4D8EE751, 0x8C52F662]),
+        ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
+         [0x4DFCCABA, 0x190A87F0, 0xC47362BA, 0xB6B5242A]),
+    ]
+    for ctr, key, want in kats7:
+        assert [int(x) for x in oracle.philox4x32(key, ctr, 7)] == want
