@@ -273,7 +273,8 @@ int rt_render_device_noalloc(const rt_scene* scene, const rt_config* cfg, uint64
  * it without counting the other blocks), "leaf_min" (lanes waiting at leaves that make the leaf block run between
  * inner-node rounds), "both_min" (when the inner-node or the leaf
  * block is due, the other of the two runs as well if this many lanes want it), "chunk_spp", "target_units" and "batches_per_wave" (how a
- * call's sample range is cut into units of work) -- none of these changes which
+ * call's sample range is cut into units of work), "quad_tiles" (1, the default: the 64 lanes of a wave start on a 4x4 block of
+ * pixels in four chunks of the sample range instead of 8x8 pixels in one, when the number of chunks allows) -- none of these changes which
  * samples are rendered; "force_global_stack" (scenes created while it is 1 keep
  * their traversal stacks in global memory, the path trees deeper than 35 levels
  * take); "force_staged_sum" (rt_render_multi adds sample-split frames through copies to the first

@@ -101,6 +101,7 @@ std::atomic<uint32_t> g_both_min{8};
 std::atomic<uint32_t> g_leaf_min{10};
 // Samples of one pixel that make a unit of work (the sample range is cut into chunks of about this size).
 std::atomic<uint32_t> g_chunk_spp{64};
+std::atomic<uint32_t> g_quad_tiles{1};
 // Fewest units of work a call is cut into (32 per lane of the chip).
 std::atomic<uint64_t> g_target_units{1u << 25};
 std::atomic<uint64_t> g_batches_per_wave{32};
@@ -269,7 +270,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   const uint32_t depth = tree_depth ? tree_depth : 1;
   const size_t reserve = lds_fixed_bytes() + 64;
   const bool stack_in_lds = depth <= max_depth && !g_force_global_stack.load();
-  const size_t stack_bytes = stack_in_lds ? (size_t)depth * kWorkgroup * 4 : 0;
+  const size_t stack_bytes = stack_in_lds ? (size_t)(depth + kStackSpareRows) * kWorkgroup * 4 : 0;
   size_t room = kLdsPerCu - stack_bytes - reserve;
   const size_t node_bytes = n_dev_nodes * sizeof(DevNode), sph_bytes = n * sizeof(DevSphere);
   const size_t aux_bytes = n * sizeof(DevSphereAux), mat_bytes = nm * 32, used_mat_bytes = n_used * 32;  // nm: records in the table
@@ -677,6 +678,10 @@ int plan_render(const Replica& rp, const CameraDev& cam, uint64_t seed, const rt
   // fewer when there are not, so that every wave gets about batches_per_wave batches.
   const uint64_t n_waves = (uint64_t)rp.num_cus * (kWorkgroup / 64);
   P.batch_chunks = (uint32_t)std::min<uint64_t>(plan.n_chunks, std::max<uint64_t>(1, n_items / (g_batches_per_wave.load() * n_waves)));
+  if (g_quad_tiles.load() && plan.n_chunks % 4 == 0) {
+    P.quad_tiles = 1;
+    P.batch_chunks = std::max(4u, P.batch_chunks & ~3u);
+  }
   P.batches_per_tile = (plan.n_chunks + P.batch_chunks - 1) / P.batch_chunks;
   P.n_batches = P.n_tiles * P.batches_per_tile;
   P.direct = plan.n_chunks == 1 ? 1u : 0u;
@@ -1419,6 +1424,10 @@ int rt_debug_set(const char* name, double value) {
     if (key == "target_units") {
       if (!(value >= 1.0 && value <= 1e12)) return fail(RT_ERR_INVALID, "rt_debug_set: target_units must be in 1 .. 1e12");
       g_target_units.store((uint64_t)value);
+      return RT_OK;
+    }
+    if (key == "quad_tiles") {
+      g_quad_tiles.store(value != 0.0 ? 1u : 0u);
       return RT_OK;
     }
     if (key == "chunk_spp") {

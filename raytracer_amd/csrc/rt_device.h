@@ -361,16 +361,20 @@ struct HybridStack {
   uint32_t k, gstride;
 };
 
+// LDS address of staged node i as an integer (LDS pointers are 32 bits wide).
+__device__ __forceinline__ uint32_t lds_node_address(lds_float4* lnodes, uint32_t i) {
+  return (uint32_t)(uintptr_t)lnodes + i * (kLdsNodeQuads * 16u);
+}
 // Writes node i (global layout q0..q3) into its LDS slot.
-// kScaled (trees that are in LDS as a whole): references to inner nodes are stored as the byte
-// offset of the node in the LDS copy, so that following one needs no multiplication.
+// kScaled (trees that are in LDS as a whole): references to inner nodes are stored as the LDS
+// address of the node's copy, so that following one needs neither a multiplication nor a base.
 template <bool kScaled>
 __device__ __forceinline__ void stage_node(lds_float4* lnodes, uint32_t i, f32x4 q0, f32x4 q1, f32x4 q2, f32x4 q3) {
   lds_float4* p = lnodes + kLdsNodeQuads * i;
   if (kScaled) {
     uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
-    if (!(r0 & kRefLeaf)) r0 *= kLdsNodeQuads * 16u;
-    if (!(r1 & kRefLeaf)) r1 *= kLdsNodeQuads * 16u;
+    if (!(r0 & kRefLeaf)) r0 = lds_node_address(lnodes, r0);
+    if (!(r1 & kRefLeaf)) r1 = lds_node_address(lnodes, r1);
     q3.x = __uint_as_float(r0);
     q3.y = __uint_as_float(r1);
   }
@@ -387,12 +391,12 @@ template <bool kScaled>
 __device__ __forceinline__ void fetch_node_lds(const TreeView& tv, uint32_t i, uint32_t offx, uint32_t offy, uint32_t offz, f32x4& X, f32x4& Y,
                                                f32x4& Z, f32x2& refs) {
   typedef __attribute__((address_space(3))) char lds_char;
-  lds_char* base = (lds_char*)tv.lnodes;
-  const uint32_t at = kScaled ? i : __umul24(i, kLdsNodeQuads * 16u);
-  X = *(lds_float4*)(base + at + offx);
-  Y = *(lds_float4*)(base + at + offy);
-  Z = *(lds_float4*)(base + at + offz);
-  refs = *(lds_float2*)(base + at + 96u);  // only the two references: no dead destination registers
+  // kScaled: i is the node's LDS address itself
+  lds_char* node = kScaled ? (lds_char*)(uintptr_t)i : (lds_char*)tv.lnodes + __umul24(i, kLdsNodeQuads * 16u);
+  X = *(lds_float4*)(node + offx);
+  Y = *(lds_float4*)(node + offy);
+  Z = *(lds_float4*)(node + offz);
+  refs = *(lds_float2*)(node + 96u);  // only the two references: no dead destination registers
 }
 __device__ __forceinline__ void fetch_node_global(const TreeView& tv, uint32_t i, f32x4& q0, f32x4& q1, f32x4& q2, f32x2& refs) {
   const f32x4* p = reinterpret_cast<const f32x4*>(tv.gnodes) + 4 * (size_t)i;
@@ -433,13 +437,14 @@ struct Trav {
   double t_best;
   float tmaxf;
   uint32_t offx, offy, offz;  // byte offset, inside a node staged in LDS, of the copy of each axis to read
-  uint32_t cur, sp;  // sp: bytes of stack in use below the top entry (see stack_slot)
+  uint32_t cur, sp;  // sp: where the stack's free slot is (see stack_slot)
   uint32_t tos;  // the top of the stack lives here; `sp` entries below it are in LDS
   int best;
 };
 
+// `sp0`: the stack pointer of an empty stack (stack_origin of the lane's stack; 0 for the four-wide walk, which counts entries).
 template <bool kWide = false>
-__device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D3 d, double t_max) {
+__device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D3 d, double t_max, uint32_t sp0 = 0u) {
   tr.o = o;
   tr.d = d;
   tr.q = ray_box(o, d, tv.bound);
@@ -456,27 +461,31 @@ __device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D
     tr.offz = tr.q.rz < 0.0f ? 80u : 64u;
   }
   tr.cur = tv.root;
-  tr.sp = 0;
+  tr.sp = sp0;
   tr.tos = kRefDone;  // popping the bottom entry ends the traversal
   tr.best = -1;
 }
 
 // The next node is already in a register when it is needed; the entry below it is
-// fetched from LDS behind the node test that follows.  `sp` counts in bytes (entries times the
-// distance between a lane's entries), so that a slot's address is one add away.
-__device__ __forceinline__ lds_u32* stack_slot(lds_u32* stack, uint32_t byte_offset) {
-  typedef __attribute__((address_space(3))) char lds_char;
-  return (lds_u32*)((lds_char*)stack + byte_offset);
-}
+// fetched from the stack behind the node test that follows.
+// A stack in LDS is walked by address: `sp` is the LDS address of the free slot above the entries in use (entries of a
+// lane are kWorkgroup words apart), so that a slot is reached without an add.  One row below the bottom is part of
+// the stack's allocation (kStackSpareRows): the pop that ends a traversal moves `sp` there and reads a word nobody looks at.
+// A stack in global memory counts `sp` in bytes from its bottom and stops there.
+__device__ __forceinline__ uint32_t stack_origin(lds_u32* stack) { return (uint32_t)(uintptr_t)stack; }
+__device__ __forceinline__ uint32_t stack_origin(uint32_t*) { return 0u; }
+__device__ __forceinline__ lds_u32* stack_slot(lds_u32*, uint32_t sp) { return (lds_u32*)(uintptr_t)sp; }
 __device__ __forceinline__ uint32_t* stack_slot(uint32_t* stack, uint32_t byte_offset) {
   return (uint32_t*)((char*)stack + byte_offset);
 }
+__device__ __forceinline__ uint32_t stack_down(lds_u32*, uint32_t sp, uint32_t bytes) { return sp - bytes; }
+__device__ __forceinline__ uint32_t stack_down(uint32_t*, uint32_t sp, uint32_t bytes) { return __builtin_elementwise_sub_sat(sp, bytes); }
 template <class StackPtr>
 __device__ __forceinline__ void trav_pop(Trav& tr, StackPtr stack, uint32_t stride) {
-  // With nothing below the top (sp == 0) the top is kRefDone, the traversal ends with this pop and
+  // With nothing below the top the top is kRefDone, the traversal ends with this pop and
   // what is read into the top is never looked at: no need to tell that case apart.
   tr.cur = tr.tos;
-  tr.sp = __builtin_elementwise_sub_sat(tr.sp, 4u * stride);
+  tr.sp = stack_down(stack, tr.sp, 4u * stride);
   tr.tos = *stack_slot(stack, tr.sp);
 }
 template <class StackPtr>
@@ -566,7 +575,7 @@ __device__ __forceinline__ void node_apply(Trav& tr, const NodeChoice& c, StackP
   // sp then moves up (both children hit).  The stack has a slot to spare for it.
   *stack_slot(stack, tr.sp) = tr.tos;
   if (!c.both && !c.any) {  // c.next was the top of the stack: bring up the entry below it (see trav_pop for sp == 0)
-    tr.sp = __builtin_elementwise_sub_sat(tr.sp, 4u * stride);
+    tr.sp = stack_down(stack, tr.sp, 4u * stride);
     tr.tos = *stack_slot(stack, tr.sp);
   }
   tr.sp += c.both ? 4u * stride : 0u;
@@ -849,7 +858,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
   lds_double2* lsph = (lds_double2*)(lnodes + (kWide ? kWideLdsStride / 16 : kLdsNodeQuads) * sc.n_nodes_lds);
   lds_double2* laux = lsph + 2 * sc.n_spheres_lds;
   lds_double2* lmat = laux + sc.n_aux_lds;
-  lds_u32* stack_base = (lds_u32*)(lmat + 2 * sc.n_materials_lds);
+  lds_u32* stack_base = (lds_u32*)(lmat + 2 * sc.n_materials_lds) + (kWide ? 0u : kStackSpareRows * wg);
   const f32x4* gn = reinterpret_cast<const f32x4*>(sc.nodes);
   const f64x2* gs = reinterpret_cast<const f64x2*>(sc.spheres);
   const f64x2* ga = reinterpret_cast<const f64x2*>(sc.aux);
@@ -884,7 +893,8 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
   im.tv.n_sph_lds = sc.n_spheres_lds;
   im.tv.n_aux_lds = sc.n_aux_lds;
   im.tv.n_mat_lds = sc.n_materials_lds;
-  im.tv.root = sc.root;
+  // a tree that is in LDS as a whole is walked by LDS addresses (see stage_node)
+  im.tv.root = (kAllLds && !kWide && !(sc.root & kRefLeaf)) ? lds_node_address(lnodes, sc.root) : sc.root;
   im.tv.bound = sc.bound;
   im.tv.single_leaves = sc.single_leaves != 0u;
   im.cam.p = lcam;

@@ -21,7 +21,9 @@ __global__ __launch_bounds__(kWorkgroup) void trace_batch_kernel(SceneDev sc, co
     D3 o = d3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
     D3 d = normalize(d3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));  // Ray::new, src/ray.rs:16-23
     Trav tr;
-    trav_begin<kWide>(tr, tv, o, d, t_max);
+    uint32_t sp0 = 0u;
+    if constexpr (!kWide) sp0 = kGStack ? 0u : stack_origin(im.stack_base + threadIdx.x);
+    trav_begin<kWide>(tr, tv, o, d, t_max, sp0);
     uint32_t n_steps = 0, n_tests = 0;
     if constexpr (kWide)
       trav_run_wide(tr, tv, HybridStack{im.stack_base + threadIdx.x, sc.gstack + gtid, sc.lds_stack, sc.gstack_stride}, t_min, n_steps, n_tests);
@@ -180,6 +182,12 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
   };
   const uint32_t stack_stride = kGStack ? P.sc.gstack_stride : kWorkgroup;
 #define RTA_STACK stack_of_lane()
+  auto empty_stack = [&]() {  // the stack pointer a traversal starts with
+    if constexpr (kWide)
+      return 0u;
+    else
+      return stack_origin(stack_of_lane());
+  };
   const uint32_t lane = threadIdx.x & 63u;
   const double t_min = 1e-3;  // src/camera.rs:102
   const float tminf = f32_below(t_min);
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           if (scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd)) {  // None = absorbed, src/camera.rs:108-110
             thr = thr * att;
             if (--depth_left != 0) {  // depth exhausted: the path contributes nothing (src/camera.rs:99-101)
-              trav_begin<kWide>(tr, tv, h.p, nd, __builtin_inf());  // HitRecord::ray, src/hit.rs:29-31
+              trav_begin<kWide>(tr, tv, h.p, nd, __builtin_inf(), empty_stack());  // HitRecord::ray, src/hit.rs:29-31
               ended = false;
             }
           }
@@ -298,8 +306,16 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
             const bool from_old = k < old_avail;
             const uint32_t rel = from_old ? old_next + k - old_base : new_first + (k - old_avail) - wave_base;  // unit within its tile
             if (from_old || wave_base + rel < wave_end) {
-              const uint32_t origin = from_old ? old_origin : wave_origin, chunk = rel >> 6;
-              const uint32_t i = (origin & 0xffffu) + (rel & 7u), j = (origin >> 16) + ((rel >> 3) & 7u);
+              const uint32_t origin = from_old ? old_origin : wave_origin;
+              // 64 consecutive units are the tile's 8x8 pixels of one chunk, or one quarter of the tile (4x4 pixels) in four
+              // chunks: the lanes of a wave then look at a quarter of the solid angle
+              uint32_t chunk = rel >> 6, io = rel & 7u, jo = (rel >> 3) & 7u;
+              if (P.quad_tiles) {
+                io = (rel & 3u) | ((rel >> 4) & 4u);
+                jo = ((rel >> 2) & 3u) | ((rel >> 5) & 4u);
+                chunk = ((rel >> 4) & 3u) | ((rel >> 8) << 2);
+              }
+              const uint32_t i = (origin & 0xffffu) + io, j = (origin >> 16) + jo;
               unit = chunk;
               pij = i | (j << 16);
               acc = d3(0.0, 0.0, 0.0);
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
             camera_ray(im.cam, P.cam.width, P.cam.defocus != 0, P.seed_lo, P.seed_hi, RTA_I, RTA_J, s, o, d);
             thr = d3(1.0, 1.0, 1.0);
             depth_left = P.cam.max_depth;
-            trav_begin<kWide>(tr, tv, o, d, __builtin_inf());
+            trav_begin<kWide>(tr, tv, o, d, __builtin_inf(), empty_stack());
           }
         }
       }
@@ -558,7 +574,7 @@ size_t tree_lds_bytes(const SceneDev& sc) {
     return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * kWideLdsStride + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
            (size_t)sc.n_materials_lds * 32 + (size_t)sc.lds_stack * kWorkgroup * 4;
   return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * lds_node_bytes() + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
-         (size_t)sc.n_materials_lds * 32 + (sc.stack_in_lds ? (size_t)sc.stack_cap * kWorkgroup * 4 : 0);
+         (size_t)sc.n_materials_lds * 32 + (sc.stack_in_lds ? (size_t)(sc.stack_cap + kStackSpareRows) * kWorkgroup * 4 : 0);
 }
 
 static bool all_in_lds(const SceneDev& sc) {

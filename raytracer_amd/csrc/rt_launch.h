@@ -59,6 +59,7 @@ struct RenderParams {
   uint32_t n_units;    // 64 x tiles x chunks
   uint32_t batch_chunks, batches_per_tile, n_batches;  // a wave takes batch_chunks chunks of one tile at a time from the global counter
   uint32_t direct;     // 1: out is the image and is added to; 0: out is the partial-sum buffer and is overwritten
+  uint32_t quad_tiles; // 1: 64 consecutive units of a tile are a 4x4 block of pixels x 4 chunks (n_chunks and batch_chunks are multiples of 4); 0: 8x8 pixels x 1 chunk
   uint32_t inner_min;  // a wave runs the inner-node block while at least this many of its lanes want it
   uint32_t leaf_min;   // inside a run of inner-node rounds the leaf block runs as soon as this many lanes wait at leaves
   uint32_t both_min;   // when a traversal block (inner or leaf) is due, the other one runs too if this many lanes want it
@@ -70,6 +71,8 @@ struct RenderParams {
 // profiling variant only: [5+2k] runs and [6+2k] active lanes of block k, [13+k] shader-clock
 // cycles of block k, [17] cycles of whole work items.
 constexpr int kRenderCounters = 18;
+// Rows (one word per lane) of a two-wide tree's LDS stack below its bottom entry: see stack_slot in rt_device.h.
+constexpr uint32_t kStackSpareRows = 1;
 
 // Dynamic LDS a tree-walking kernel needs for this scene (includes the camera block).
 size_t tree_lds_bytes(const SceneDev& sc);

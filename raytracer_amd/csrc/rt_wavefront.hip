@@ -70,7 +70,9 @@ __global__ __launch_bounds__(kWorkgroup) void wf_trace_kernel(WfParams P) {
   for (uint32_t k = gtid; k < n; k += gridDim.x * kWorkgroup) {
     const D3 o = d3(P.in.v[0][k], P.in.v[1][k], P.in.v[2][k]), d = d3(P.in.v[3][k], P.in.v[4][k], P.in.v[5][k]);
     Trav tr;
-    trav_begin<kWide>(tr, tv, o, d, __builtin_inf());
+    uint32_t sp0 = 0u;
+    if constexpr (!kWide) sp0 = stack_origin(im.stack_base + threadIdx.x);
+    trav_begin<kWide>(tr, tv, o, d, __builtin_inf(), sp0);
     uint32_t n_steps = 0, n_tests = 0;
     if constexpr (kWide)
       trav_run_wide(tr, tv, HybridStack{im.stack_base + threadIdx.x, P.sc.gstack + gtid, P.sc.lds_stack, P.sc.gstack_stride}, 1e-3, n_steps, n_tests);
