@@ -111,6 +111,12 @@ def main():
     ap.add_argument("--force-distributed", action="store_true", help="set up the process group and run the collectives even with one rank (a rehearsal of the N > 1 path on one GPU)")
     args = ap.parse_args()
 
+    # Libraries write banners on the process's standard output (RCCL prints its version there when the process group
+    # starts); the contract is one JSON line, so everything but that line goes to standard error.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -267,7 +273,10 @@ def main():
                 "measured_cycles_per_instruction_alone": "4.0-4.5 (fma, min/max, compare, select, f64), 2.5 (32-bit add, mul, xor, mov)",
                 "replayed_from": traffic["file"] + ", profiles/r01_valu_rate.txt",
             }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if distributed:
         dist.destroy_process_group()
     world.close()
