@@ -150,22 +150,55 @@ __device__ __forceinline__ void sincos_2pi(double u, double& s, double& c) {
   c = ((k + 1) & 2) ? -c1 : c1;
 }
 
+// The same through a table of sin and cos at the 64th parts of a turn (in LDS, filled by stage_scene with the
+// function above): the remainder is at most 1/128 of a turn, where four terms of each series reach double
+// precision, and the angle-sum formulas put the two together.  About 2 ulp; half the instructions.
+constexpr uint32_t kTrigEntries = 64;
+struct TrigSeries {};  // no table: the polynomials over a quarter turn
+struct TrigTable {
+  __attribute__((address_space(3))) double* tab;  // kTrigEntries x (sin, cos)
+};
+__device__ __forceinline__ void sincos_2pi(double u, double& s, double& c, TrigSeries) { sincos_2pi(u, s, c); }
+__device__ __forceinline__ void sincos_2pi(double u, double& s, double& c, TrigTable t) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) d2 lds_d2;
+  const double q = rint((double)kTrigEntries * u);           // 0..64
+  const double f = fma(q, -1.0 / kTrigEntries, u);           // exact, |f| <= 1/128
+  const uint32_t k = (uint32_t)(int)q & (kTrigEntries - 1u);
+  const d2 sc = *(lds_d2*)(t.tab + 2u * k);
+  const double a = f * local_const(6.28318530717958647692528676655900577);
+  const double z = a * a;
+  double ps = local_const(-1.0 / 5040.0);
+  ps = fma(ps, z, local_const(1.0 / 120.0));
+  ps = fma(ps, z, local_const(-1.0 / 6.0));
+  const double sa = fma(a * z, ps, a);
+  double pc = local_const(1.0 / 40320.0);
+  pc = fma(pc, z, local_const(-1.0 / 720.0));
+  pc = fma(pc, z, local_const(1.0 / 24.0));
+  pc = fma(pc, z, -0.5);
+  const double ca = fma(pc, z, 1.0);
+  s = fma(sc.x, ca, sc.y * sa);
+  c = fma(sc.y, ca, -(sc.x * sa));
+}
+
 // Uniform point on the unit sphere from two uniforms: z = 1-2u0, phi = 2 pi u1.
 // Same distribution as normalising a point drawn uniformly in the unit ball
 // (vector::random_unit, src/vector.rs:16-27).
-__device__ __forceinline__ D3 unit_from_uniforms(double u0, double u1) {
+template <class Trig = TrigSeries>
+__device__ __forceinline__ D3 unit_from_uniforms(double u0, double u1, Trig trig = Trig{}) {
   double z = 1.0 - 2.0 * u0;
   double rxy = sqrt_plain(fmax(0.0, 1.0 - z * z));
   double s, c;
-  sincos_2pi(u1, s, c);
+  sincos_2pi(u1, s, c, trig);
   return d3(rxy * c, rxy * s, z);
 }
 // Uniform point in the unit disk: r = sqrt(u0), phi = 2 pi u1
 // (vector::random_within_unit_disk, src/vector.rs:29-40).
-__device__ __forceinline__ void disk_from_uniforms(double u0, double u1, double& px, double& py) {
+template <class Trig = TrigSeries>
+__device__ __forceinline__ void disk_from_uniforms(double u0, double u1, double& px, double& py, Trig trig = Trig{}) {
   double r = sqrt_plain(u0);
   double s, c;
-  sincos_2pi(u1, s, c);
+  sincos_2pi(u1, s, c, trig);
   px = r * c;
   py = r * s;
 }
@@ -188,9 +221,9 @@ struct CamLds {
   __device__ __forceinline__ D3 get(int k) const { return d3(p[k], p[k + 1], p[k + 2]); }
 };
 // Camera::get_ray (src/camera.rs:114-136) for pixel (i,j), sample s.
-template <class Cam>
+template <class Cam, class Trig = TrigSeries>
 __device__ __forceinline__ void camera_ray(const Cam& cam, uint32_t width, bool defocus, uint32_t k0, uint32_t k1, uint32_t i, uint32_t j,
-                                           uint32_t s, D3& org, D3& dir) {
+                                           uint32_t s, D3& org, D3& dir, Trig trig = Trig{}) {
   const uint32_t pixel = j * width + i;
   const D3 du = cam.get(CAM_DU), dv = cam.get(CAM_DV);
   D3 pixel_center = cam.get(CAM_PIXEL00) + ((double)i * du) + ((double)j * dv);
@@ -201,7 +234,7 @@ __device__ __forceinline__ void camera_ray(const Cam& cam, uint32_t width, bool 
   org = cam.get(CAM_CENTER);
   if (defocus) {
     double dx, dy;
-    disk_from_uniforms(u[2], u[3], dx, dy);
+    disk_from_uniforms(u[2], u[3], dx, dy, trig);
     org = org + dx * cam.get(CAM_DISK_U) + dy * cam.get(CAM_DISK_V);
   }
   dir = normalize(pixel_sample - org);
@@ -798,9 +831,9 @@ __device__ __forceinline__ Hit make_hit(const TreeView& tv, int slot, D3 o, D3 d
 // Material record (32 bytes): Lambertian/Metal (albedo.x, albedo.y)(albedo.z, fuzz);
 // Dielectric (ir, 1/ir)(r0, -) with r0 = ((1-ir)/(1+ir))^2, which is the same
 // number for ir and 1/ir.  Returns false where the reference returns None.
-template <bool kAllLds>
+template <bool kAllLds, class Trig = TrigSeries>
 __device__ __forceinline__ bool scatter(const TreeView& tv, uint32_t mat, D3 d, const Hit& h, double u0, double u1, D3& attenuation,
-                                        D3& out_dir) {
+                                        D3& out_dir, Trig trig = Trig{}) {
   const uint32_t type = mat >> 30, index = mat & 0x3fffffffu;
   f64x2 m0, m1;
   if (kAllLds || index < tv.n_mat_lds) {
@@ -829,7 +862,7 @@ __device__ __forceinline__ bool scatter(const TreeView& tv, uint32_t mat, D3 d, 
     }
   } else {
     attenuation = d3(m0.x, m0.y, m1.x);
-    D3 unit = unit_from_uniforms(u0, u1);
+    D3 unit = unit_from_uniforms(u0, u1, trig);
     if (type == 0u) {  // Lambertian
       dir = h.normal + unit;
       if (fabs(dir.x) <= 1e-6 && fabs(dir.y) <= 1e-6 && fabs(dir.z) <= 1e-6) dir = h.normal;  // near_zero, src/vector.rs:52-54
@@ -844,17 +877,19 @@ __device__ __forceinline__ bool scatter(const TreeView& tv, uint32_t mat, D3 d, 
 
 // ------------------------------------------------------------ LDS image ----
 // LDS image of a workgroup:
-//   [camera constants][top-of-tree nodes][sphere slots][slot shading data][materials][per-lane stacks]
+//   [camera constants][sin/cos table][top-of-tree nodes][sphere slots][slot shading data][materials][per-lane stacks]
 struct LdsImage {
   TreeView tv;
   CamLds cam;
+  TrigTable trig;
   lds_u32* stack_base;
 };
 
 template <bool kAllLds, bool kWide = false>
 __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const CameraDev* cam, float4* smem, uint32_t wg) {
   lds_double* lcam = (lds_double*)smem;
-  lds_float4* lnodes = (lds_float4*)(lcam + CAM_DOUBLES);
+  lds_double* ltrig = lcam + CAM_DOUBLES;
+  lds_float4* lnodes = (lds_float4*)(ltrig + 2 * kTrigEntries);
   lds_double2* lsph = (lds_double2*)(lnodes + (kWide ? kWideLdsStride / 16 : kLdsNodeQuads) * sc.n_nodes_lds);
   lds_double2* laux = lsph + 2 * sc.n_spheres_lds;
   lds_double2* lmat = laux + sc.n_aux_lds;
@@ -867,6 +902,12 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
     const uint32_t k = threadIdx.x;
     const double* src = k < 3 ? cam->center : k < 6 ? cam->pixel00 : k < 9 ? cam->du : k < 12 ? cam->dv : k < 15 ? cam->disk_u : cam->disk_v;
     lcam[k] = src[k % 3];
+  }
+  if (threadIdx.x < kTrigEntries) {
+    double sn, cs;
+    sincos_2pi((double)threadIdx.x * (1.0 / kTrigEntries), sn, cs);
+    ltrig[2 * threadIdx.x] = sn;
+    ltrig[2 * threadIdx.x + 1] = cs;
   }
   if (kWide) {  // four-wide nodes are staged as they are, 80 bytes apart
     for (uint32_t i = threadIdx.x; i < kWideStagedQuads * sc.n_nodes_lds; i += wg) {
@@ -898,6 +939,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
   im.tv.bound = sc.bound;
   im.tv.single_leaves = sc.single_leaves != 0u;
   im.cam.p = lcam;
+  im.trig.tab = ltrig;
   im.stack_base = stack_base;
   return im;
 }

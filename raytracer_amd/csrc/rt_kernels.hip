@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           double u0, u1;
           philox_pair(P.seed_lo, P.seed_hi, RTA_J * P.cam.width + RTA_I, s, P.cam.max_depth - depth_left, DOM_SCATTER, u0, u1);
           D3 att, nd;
-          if (scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd)) {  // None = absorbed, src/camera.rs:108-110
+          if (scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd, im.trig)) {  // None = absorbed, src/camera.rs:108-110
             thr = thr * att;
             if (--depth_left != 0) {  // depth exhausted: the path contributes nothing (src/camera.rs:99-101)
               trav_begin<kWide>(tr, tv, h.p, nd, __builtin_inf(), empty_stack());  // HitRecord::ray, src/hit.rs:29-31
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           }
           if (tr.cur == kRefCamera && s < s_last) {  // Camera::get_ray, src/camera.rs:147-148
             D3 o, d;
-            camera_ray(im.cam, P.cam.width, P.cam.defocus != 0, P.seed_lo, P.seed_hi, RTA_I, RTA_J, s, o, d);
+            camera_ray(im.cam, P.cam.width, P.cam.defocus != 0, P.seed_lo, P.seed_hi, RTA_I, RTA_J, s, o, d, im.trig);
             thr = d3(1.0, 1.0, 1.0);
             depth_left = P.cam.max_depth;
             trav_begin<kWide>(tr, tv, o, d, __builtin_inf(), empty_stack());
@@ -568,7 +568,7 @@ hipError_t static_scratch(int device, void** ptr, size_t* bytes) {
 // --------------------------------------------------------------- launchers ----
 size_t lds_node_bytes() { return kLdsNodeQuads * 16; }
 size_t lds_wide_node_bytes() { return kWideLdsStride; }
-size_t lds_fixed_bytes() { return CAM_DOUBLES * 8; }
+size_t lds_fixed_bytes() { return CAM_DOUBLES * 8 + kTrigEntries * 16; }  // camera constants, sin/cos table
 size_t tree_lds_bytes(const SceneDev& sc) {
   if (sc.wide)
     return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * kWideLdsStride + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
