@@ -78,36 +78,12 @@ __device__ __forceinline__ double local_const(double c) {
   return c;
 }
 
-// Square root of a finite x >= 0 that is not huge or tiny enough to need rescaling (|x| within
-// 1e-280 .. 1e280, or 0): the reciprocal-square-root instruction refined by the same Goldschmidt
-// steps and residual corrections the compiler's sqrt uses, without its range checks.
+// Square root of a finite x >= 0 that is not huge or tiny enough to need rescaling (0, or |x| within
+// 1e-280 .. 1e280): the reciprocal-square-root instruction refined by the same Goldschmidt
+// steps and residual corrections the compiler's sqrt uses, without its range checks.  A zero is lifted to 2^-1000
+// instead of being singled out afterwards (the instruction's result for 0 is infinite): its root comes out as
+// 2^-500 = 3e-151, which no sum with a number of the scene's scale can see.
 __device__ __forceinline__ double sqrt_plain(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = 0.5 * y;
-  const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  double d = fma(-g, g, x);
-  g = fma(d, h, g);
-  d = fma(-g, g, x);
-  g = fma(d, h, g);
-  return x > 0.0 ? g : 0.0;  // rsq(0) is infinite
-}
-
-// 1/sqrt(x) for a finite x > 0 that is not tiny or huge: the reciprocal-square-root instruction and
-// the refinement step the compiler's rsqrt uses, without its check for zero and infinite results.
-__device__ __forceinline__ double rsqrt_plain(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  const double e = fma(-(y * x), y, 1.0);
-  return fma(y * e, fma(e, 0.375, 0.5), y);
-}
-// A direction of the path: never the zero vector (scatter replaces a degenerate one, the camera looks somewhere).
-__device__ __forceinline__ D3 normalize(D3 a) { return rsqrt_plain(dot(a, a)) * a; }
-
-// The same for the sphere test's discriminant (x >= 0): a zero is lifted to 2^-1000 instead of being
-// singled out afterwards, so an exactly tangent ray gets a root 1e-150 off, which no sum with a
-// distance of the scene's scale can see.
-__device__ __forceinline__ double sqrt_disc(double x) {
   double xx;
   asm("v_max_f64 %0, %1, %2" : "=v"(xx) : "v"(x), "v"(0x1p-1000));
   const double y = __builtin_amdgcn_rsq(xx);
@@ -120,6 +96,19 @@ __device__ __forceinline__ double sqrt_disc(double x) {
   d = fma(-g, g, xx);
   return fma(d, h, g);
 }
+
+// 1/sqrt(x) for a finite x > 0 that is not tiny or huge: the reciprocal-square-root instruction and
+// the refinement step the compiler's rsqrt uses, without its check for zero and infinite results.
+__device__ __forceinline__ double rsqrt_plain(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(y * x), y, 1.0);
+  return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+// A direction of the path: never the zero vector (scatter replaces a degenerate one, the camera looks somewhere).
+__device__ __forceinline__ D3 normalize(D3 a) { return rsqrt_plain(dot(a, a)) * a; }
+
+// The sphere test's discriminant (x >= 0): an exactly tangent ray gets a root 1e-150 off.
+__device__ __forceinline__ double sqrt_disc(double x) { return sqrt_plain(x); }
 
 // sin and cos of 2*pi*u for u in [0,1): the argument is reduced exactly to a
 // quarter turn q and a remainder |f| <= 1/8 of a turn, then the classic
@@ -849,8 +838,11 @@ __device__ __forceinline__ bool scatter(const TreeView& tv, uint32_t mat, D3 d, 
     attenuation = d3(1.0, 1.0, 1.0);
     double ratio = h.front ? m0.y : m0.x;  // ir^-1 entering, ir leaving (src/material.rs:52)
     double cos_theta = fmin(-dot(d, h.normal), 1.0);
-    double sin_theta = sqrt_plain(fmax(0.0, 1.0 - cos_theta * cos_theta));
-    bool cannot_refract = ratio * sin_theta > 1.0;
+    // ratio * sin_theta > 1 (src/material.rs:54-55) decided on the squares, which need no root; where those are too
+    // close to 1 to tell (never, in practice: the wave skips it) the reference's own expression decides
+    const double sin2 = fmax(0.0, 1.0 - cos_theta * cos_theta), k2 = (ratio * ratio) * sin2;
+    bool cannot_refract = k2 > 1.0;
+    if (fabs(k2 - 1.0) < 1e-12) cannot_refract = ratio * sqrt_plain(sin2) > 1.0;
     double x = 1.0 - cos_theta, x2 = x * x;
     double reflectance = m1.x + (1.0 - m1.x) * (x2 * x2 * x);  // Schlick, src/material.rs:45-50
     if (cannot_refract || reflectance > u0) {
