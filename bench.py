@@ -270,8 +270,8 @@ def main():
                 "valu_wave_instructions_per_launch": issue["valu_wave_instructions_per_launch"],
                 "simd_cycles_per_valu_instruction": issue["simd_cycles_per_valu_instruction"],
                 "mean_active_lanes_per_valu_instruction": issue["mean_active_lanes_per_valu_instruction"],
-                "measured_cycles_per_instruction_alone": "4.0-4.5 (fma, min/max, compare, select, f64), 2.5 (32-bit add, mul, xor, mov)",
-                "replayed_from": traffic["file"] + ", profiles/r01_valu_rate.txt",
+                "measured_cycles_per_instruction_alone": "2.5-2.7 (f32 add, mul, fma; 32-bit add, logic, mov), 4.1-4.6 (min/max, compare, select, shift, f64)",
+                "replayed_from": traffic["file"] + ", profiles/r02_valu_rate.txt, profiles/r02_bank_rate.txt",
             }
         sys.stdout.flush()
         os.dup2(json_fd, 1)

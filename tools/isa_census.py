@@ -3,8 +3,9 @@
   hipcc ... -S --cuda-device-only -o k.s raytracer_amd/csrc/rt_kernels.hip
   python tools/isa_census.py k.s _ZN3rta13render_kernelILb1ELb0ELb0ELb1ELb0EEEvNS_12RenderParamsE [min depth]
 Per basic block at loop depth >= min depth (default 3: the traversal rounds): instructions by class.
-full = vector instructions of the 4-cycle class (fma, min/max, compare, select, f64, mad, perm, cvt, lshl_add),
-simple = vector 32-bit add/sub/and/or/xor/mov/mul_f32/add_f32 (2.6 cycles measured)."""
+slow = vector instructions that occupy the SIMD for 4.1-4.6 cycles per wave (min/max, compare, select, shift, f64, mad, perm, cvt, lshl_add),
+fma32 = f32 add, multiply and multiply-add (2.5 cycles), simple = 32-bit integer add/sub/and/or/xor/mov (2.6 cycles);
+measured: profiles/r02_valu_rate.txt, profiles/r02_bank_rate.txt."""
 import re
 import sys
 from collections import Counter
@@ -14,12 +15,13 @@ min_depth = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 text = open(path).read()
 body = text[text.index("\n" + kernel + ":"):]
 body = body[:body.index("s_endpgm")]
-SIMPLE = re.compile(r"v_(add_u32|sub_u32|subrev_u32|and_b32|or_b32|xor_b32|mov_b32|mul_f32|add_f32|sub_f32|not_b32)(_e32|_e64|_sdwa|_dpp)?$")
+SIMPLE = re.compile(r"v_(add_u32|sub_u32|subrev_u32|and_b32|or_b32|xor_b32|mov_b32|not_b32)(_e32|_e64|_sdwa|_dpp)?$")
+FMA32 = re.compile(r"v_(fma_f32|fmac_f32|mac_f32|mul_f32|add_f32|sub_f32|subrev_f32)(_e32|_e64|_sdwa|_dpp)?$")
 
 
 def klass(op):
     if op.startswith("v_"):
-        return "simple" if SIMPLE.match(op) else "full"
+        return "simple" if SIMPLE.match(op) else "fma32" if FMA32.match(op) else "slow"
     if op.startswith("ds_"):
         return "lds"
     if op.startswith(("global_", "flat_", "buffer_", "scratch_")):
@@ -56,7 +58,7 @@ for line in body.splitlines():
         continue
     cur[klass(s.split()[0])] += 1
 blocks.append([name, depth, cur])
-cols = ["full", "simple", "lds", "vmem", "salu", "branch", "wait"]
+cols = ["slow", "fma32", "simple", "lds", "vmem", "salu", "branch", "wait"]
 print("%-12s %5s " % ("block", "depth") + " ".join("%7s" % c for c in cols))
 tot = Counter()
 for name, depth, c in blocks:
