@@ -685,6 +685,13 @@ int plan_render(const Replica& rp, const CameraDev& cam, uint64_t seed, const rt
   P.batches_per_tile = (plan.n_chunks + P.batch_chunks - 1) / P.batch_chunks;
   P.n_batches = P.n_tiles * P.batches_per_tile;
   P.direct = plan.n_chunks == 1 ? 1u : 0u;
+  {  // the node tests' time scale: the scene's extent and the camera's distance from the origin, with a factor 16 to spare
+    float extent = std::max(rp.dev.bound, 1e-30f);
+    for (int k = 0; k < 3; ++k) extent = std::max(extent, (float)std::fabs(cam.center[k]));
+    int e = 0;
+    (void)std::frexp(extent, &e);  // extent < 2^e
+    P.time_scale = std::ldexp(1.0f, -(e + 5));
+  }
   P.inner_min = g_inner_min.load();
   P.both_min = g_both_min.load();
   P.leaf_min = g_leaf_min.load();

@@ -253,30 +253,59 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// The tests run in a shifted and scaled time, tau = (t - t0) * scale: t0 is the start of the query's interval
+// (so that "not before the interval" is tau >= 0, which the clamp modifier of a multiply-add gives for free, see
+// fma_clamp) and `scale` a power of two that brings the times of the scene below 1 (the clamp also cuts at 1:
+// an entry time beyond that can only make a test answer "hit" more often).  Subtracting t0 rounds once more
+// (covered by the pad: 2 * t0 more half-ulps); scaling by a power of two does not round.
+struct TimeFrame {
+  float t0, scale;
+};
+__device__ __forceinline__ TimeFrame time_frame(double t_min, float scale) {
+  float f = (float)t_min;
+  if ((double)f > t_min) f = nextafterf(f, -__builtin_inff());  // the largest f32 <= t_min
+  return TimeFrame{f, scale};
+}
+// A power of two that brings the times a ray can spend in a scene of this extent (and 16 times more) below 1.
+__device__ __forceinline__ float time_scale_for(float bound) {
+  int e;
+  (void)frexpf(fmaxf(bound, 1e-30f), &e);  // bound < 2^e
+  return ldexpf(1.0f, -(e + 5));
+}
+// tau of a time t >= t0, rounded up (the far end of an interval)
+__device__ __forceinline__ float tau_above(const TimeFrame& tf, double t) {
+  if (!(t < 3.0e38)) return __builtin_inff();
+  const double v = (t - (double)tf.t0) * (double)tf.scale;
+  float f = (float)v;
+  return ((double)f < v) ? nextafterf(f, __builtin_inff()) : f;
+}
+
 struct RayBox {
-  float rx, ry, rz;  // reciprocal direction
+  float rx, ry, rz;  // reciprocal direction, times the time scale
   f32x2 cx, cy, cz;  // (c_lo, c_hi) per axis: constants for the box's low and high plane
   f32x2 nx, ny, nz;  // (c_near, c_far) per axis: the same two constants by the order the ray meets the planes
 };
 
-__device__ __forceinline__ void ray_box_axis(double o, double d, float bound, float& rf, f32x2& c2, f32x2& s2) {
+__device__ __forceinline__ void ray_box_axis(double o, double d, float bound, TimeFrame tf, float& rf, f32x2& c2, f32x2& s2) {
   float df = (float)d;
-  float r = __builtin_amdgcn_rcpf(df);
+  float r1 = __builtin_amdgcn_rcpf(df);
+  float r = r1 * tf.scale;  // everything below is in scaled time (a power of two: no rounding)
   float of = (float)o;
   float orf = of * r;
-  float e = RTA_U24 * (6.0f * bound * fabsf(r) + 12.0f * fabsf(orf));
-  bool ok = fabsf(r) <= 1e18f;  // false for inf and NaN too
-  float cn = -orf - e, cf = -orf + e;
+  const float t0s = tf.t0 * tf.scale;
+  float e = RTA_U24 * (6.0f * bound * fabsf(r) + 12.0f * fabsf(orf) + 2.0f * fabsf(t0s));
+  bool ok = fabsf(r1) <= 1e18f;  // false for inf and NaN too
+  float cn = -orf - (e + t0s), cf = -orf + (e - t0s);
   bool neg = r < 0.0f;
   rf = ok ? r : 0.0f;
   c2 = ok ? (neg ? f32x2{cf, cn} : f32x2{cn, cf}) : f32x2{-__builtin_inff(), __builtin_inff()};
   s2 = ok ? f32x2{cn, cf} : f32x2{-__builtin_inff(), __builtin_inff()};
 }
-__device__ __forceinline__ RayBox ray_box(D3 o, D3 d, float bound) {
+__device__ __forceinline__ RayBox ray_box(D3 o, D3 d, float bound, TimeFrame tf) {
   RayBox q;
-  ray_box_axis(o.x, d.x, bound, q.rx, q.cx, q.nx);
-  ray_box_axis(o.y, d.y, bound, q.ry, q.cy, q.ny);
-  ray_box_axis(o.z, d.z, bound, q.rz, q.cz, q.nz);
+  ray_box_axis(o.x, d.x, bound, tf, q.rx, q.cx, q.nx);
+  ray_box_axis(o.y, d.y, bound, tf, q.ry, q.cy, q.ny);
+  ray_box_axis(o.z, d.z, bound, tf, q.rz, q.cz, q.nz);
   return q;
 }
 __device__ __forceinline__ float f32_below(double v) {  // largest f32 <= v
@@ -290,7 +319,13 @@ __device__ __forceinline__ float f32_above(double v) {  // smallest f32 >= v
 // Some f32 >= v for a finite v > 0 well inside the f32 range: the nearest f32 moved one step up, without
 // looking at which way the conversion rounded (at most two steps above v instead of at most one).
 __device__ __forceinline__ float f32_beyond(double v) { return __uint_as_float(__float_as_uint((float)v) + 1u); }
-// One box given as (lo, hi) pairs per axis: does the ray cross it within [tminf, tmaxf]?
+// Some tau >= that of a time t inside the interval, in f32: t converted and moved one step up (>= t), scaled and
+// shifted by one multiply-add (one rounding), and moved one step up again.
+__device__ __forceinline__ float tau_beyond(const TimeFrame& tf, double t) {
+  const float t_up = __uint_as_float(__float_as_uint((float)t) + 1u);
+  return __uint_as_float(__float_as_uint(fmaf(t_up, tf.scale, -tf.t0 * tf.scale)) + 1u);
+}
+// One box given as (lo, hi) pairs per axis: does the ray cross it within [tminf, tmaxf] (in the ray's time frame)?
 __device__ __forceinline__ bool box_test(const RayBox& q, f32x2 bx, f32x2 by, f32x2 bz, float tminf, float tmaxf, float& tn) {
   f32x2 tx = f32x2{fmaf(bx.x, q.rx, q.cx.x), fmaf(bx.y, q.rx, q.cx.y)};
   f32x2 ty = f32x2{fmaf(by.x, q.ry, q.cy.x), fmaf(by.y, q.ry, q.cy.y)};
@@ -322,15 +357,22 @@ __device__ __forceinline__ float min3_raw(float a, float b, float c) {
   asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// a * b + c cut to [0, 1] by the instruction's output modifier (a NaN comes out as 0)
+__device__ __forceinline__ float fma_clamp(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 // Both boxes of a node at once, from the direction-sorted planes (entry planes of box 0 and 1 in
 // .xy, exit planes in .zw).  Scalar multiply-adds: the packed two-wide form measured slower here.
-__device__ __forceinline__ void box_pair_sorted(const RayBox& q, f32x4 X, f32x4 Y, f32x4 Z, float tminf, float tmaxf, float& tn0, float& tn1,
+// The start of the interval is time 0 of the ray's frame: the clamp on one of the three entry times stands for it.
+__device__ __forceinline__ void box_pair_sorted(const RayBox& q, f32x4 X, f32x4 Y, f32x4 Z, float tmaxf, float& tn0, float& tn1,
                                                 bool& h0, bool& h1) {
   const f32x2 nx = {fmaf(X.x, q.rx, q.nx.x), fmaf(X.y, q.rx, q.nx.x)}, fx = {fmaf(X.z, q.rx, q.nx.y), fmaf(X.w, q.rx, q.nx.y)};
   const f32x2 ny = {fmaf(Y.x, q.ry, q.ny.x), fmaf(Y.y, q.ry, q.ny.x)}, fy = {fmaf(Y.z, q.ry, q.ny.y), fmaf(Y.w, q.ry, q.ny.y)};
-  const f32x2 nz = {fmaf(Z.x, q.rz, q.nz.x), fmaf(Z.y, q.rz, q.nz.x)}, fz = {fmaf(Z.z, q.rz, q.nz.y), fmaf(Z.w, q.rz, q.nz.y)};
-  tn0 = max3_raw(nx.x, ny.x, max_raw(nz.x, tminf));
-  tn1 = max3_raw(nx.y, ny.y, max_raw(nz.y, tminf));
+  const f32x2 nz = {fma_clamp(Z.x, q.rz, q.nz.x), fma_clamp(Z.y, q.rz, q.nz.x)}, fz = {fmaf(Z.z, q.rz, q.nz.y), fmaf(Z.w, q.rz, q.nz.y)};
+  tn0 = max3_raw(nx.x, ny.x, nz.x);
+  tn1 = max3_raw(nx.y, ny.y, nz.y);
   const float tf0 = min3_raw(fx.x, fy.x, min_raw(fz.x, tmaxf));
   const float tf1 = min3_raw(fx.y, fy.y, min_raw(fz.y, tmaxf));
   h0 = tn0 <= tf0;
@@ -372,6 +414,7 @@ struct TreeView {
   uint32_t n_lds, n_sph_lds, n_aux_lds, n_mat_lds;
   uint32_t root;
   float bound;
+  TimeFrame time;      // the frame the node tests run in: the start of the queries' interval and the scene's time scale
   bool single_leaves;  // every leaf holds exactly one sphere
 };
 
@@ -469,9 +512,9 @@ template <bool kWide = false>
 __device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D3 d, double t_max, uint32_t sp0 = 0u) {
   tr.o = o;
   tr.d = d;
-  tr.q = ray_box(o, d, tv.bound);
+  tr.q = ray_box(o, d, tv.bound, tv.time);
   tr.t_best = t_max;
-  tr.tmaxf = (t_max < 3.0e38) ? f32_above(t_max) : __builtin_inff();
+  tr.tmaxf = tau_above(tv.time, t_max);
   // The copy must match the sign the node test sees, which is that of the f32 reciprocal.
   if (kWide) {  // four-wide nodes: per axis, the byte offset of the word of planes met first
     tr.offx = tr.q.rx < 0.0f ? 16u : 0u;
@@ -519,19 +562,19 @@ __device__ __forceinline__ void trav_push(Trav& tr, StackPtr stack, uint32_t str
 
 // One inner node: test both children, descend into the first one hit.
 template <bool kAllLds, class StackPtr>
-__device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride, float tminf) {
+__device__ __forceinline__ void trav_inner_step(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride) {
   f32x2 q3;
   bool h0, h1;
   float tn0 = 0.0f, tn1 = 0.0f;
   if (kAllLds || tr.cur < tv.n_lds) {
     f32x4 X, Y, Z;
     fetch_node_lds<kAllLds>(tv, tr.cur, tr.offx, tr.offy, tr.offz, X, Y, Z, q3);
-    box_pair_sorted(tr.q, X, Y, Z, tminf, tr.tmaxf, tn0, tn1, h0, h1);
+    box_pair_sorted(tr.q, X, Y, Z, tr.tmaxf, tn0, tn1, h0, h1);
   } else {
     f32x4 q0, q1, q2;
     fetch_node_global(tv, tr.cur, q0, q1, q2, q3);
-    h0 = box_test(tr.q, f32x2{q0.x, q0.y}, f32x2{q1.x, q1.y}, f32x2{q2.x, q2.y}, tminf, tr.tmaxf, tn0);
-    h1 = box_test(tr.q, f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, tminf, tr.tmaxf, tn1);
+    h0 = box_test(tr.q, f32x2{q0.x, q0.y}, f32x2{q1.x, q1.y}, f32x2{q2.x, q2.y}, 0.0f, tr.tmaxf, tn0);
+    h1 = box_test(tr.q, f32x2{q0.z, q0.w}, f32x2{q1.z, q1.w}, f32x2{q2.z, q2.w}, 0.0f, tr.tmaxf, tn1);
   }
   const uint32_t ref0 = __float_as_uint(q3.x), ref1 = __float_as_uint(q3.y);
   const bool swap = tn1 < tn0;  // of two children that are hit, the one entered first is visited first
@@ -572,14 +615,14 @@ struct NodeChoice {
   bool both, any;
 };
 template <bool kAllLds>
-__device__ __forceinline__ NodeChoice node_choose(const Trav& tr, const NodeData& n, float tminf) {
+__device__ __forceinline__ NodeChoice node_choose(const Trav& tr, const NodeData& n) {
   bool h0, h1;
   float tn0 = 0.0f, tn1 = 0.0f;
   if (kAllLds || n.sorted) {
-    box_pair_sorted(tr.q, n.a, n.b, n.c, tminf, tr.tmaxf, tn0, tn1, h0, h1);
+    box_pair_sorted(tr.q, n.a, n.b, n.c, tr.tmaxf, tn0, tn1, h0, h1);
   } else {
-    h0 = box_test(tr.q, f32x2{n.a.x, n.a.y}, f32x2{n.b.x, n.b.y}, f32x2{n.c.x, n.c.y}, tminf, tr.tmaxf, tn0);
-    h1 = box_test(tr.q, f32x2{n.a.z, n.a.w}, f32x2{n.b.z, n.b.w}, f32x2{n.c.z, n.c.w}, tminf, tr.tmaxf, tn1);
+    h0 = box_test(tr.q, f32x2{n.a.x, n.a.y}, f32x2{n.b.x, n.b.y}, f32x2{n.c.x, n.c.y}, 0.0f, tr.tmaxf, tn0);
+    h1 = box_test(tr.q, f32x2{n.a.z, n.a.w}, f32x2{n.b.z, n.b.w}, f32x2{n.c.z, n.c.w}, 0.0f, tr.tmaxf, tn1);
   }
   const uint32_t ref0 = __float_as_uint(n.q3.x), ref1 = __float_as_uint(n.q3.y);
   const bool swap = tn1 < tn0;
@@ -604,16 +647,16 @@ __device__ __forceinline__ void node_apply(Trav& tr, const NodeChoice& c, StackP
   tr.tos = c.both ? c.far : tr.tos;
 }
 template <bool kAllLds, class StackPtr>
-__device__ __forceinline__ uint32_t trav_inner_pair(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride, float tminf) {
+__device__ __forceinline__ uint32_t trav_inner_pair(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride) {
   const NodeData na = node_fetch<kAllLds>(tr, tv, tr.cur);
-  const NodeChoice ca = node_choose<kAllLds>(tr, na, tminf);
+  const NodeChoice ca = node_choose<kAllLds>(tr, na);
   const bool go = !(ca.next & kRefLeaf);
   NodeData nb;
   if (go) nb = node_fetch<kAllLds>(tr, tv, ca.next);
   node_apply(tr, ca, stack, stride);
   tr.cur = ca.next;
   if (go) {
-    const NodeChoice cb = node_choose<kAllLds>(tr, nb, tminf);
+    const NodeChoice cb = node_choose<kAllLds>(tr, nb);
     node_apply(tr, cb, stack, stride);
     tr.cur = cb.next;
     return 2u;
@@ -656,7 +699,7 @@ __device__ __forceinline__ void trav_push(Trav& tr, const HybridStack& st, uint3
   tr.tos = ref;
 }
 // One four-wide node: test the four child boxes, continue with the one entered first, set the others aside.
-__device__ __forceinline__ void trav_wide_step(Trav& tr, const TreeView& tv, const HybridStack& st, float tminf) {
+__device__ __forceinline__ void trav_wide_step(Trav& tr, const TreeView& tv, const HybridStack& st) {
   // tr.offx/y/z: 16 where the ray travels down the axis (its near planes are the high ones), else 0
   f32x4 NX, FX, NY, FY, NZ, FZ;
   u32x4 refs;
@@ -682,10 +725,10 @@ __device__ __forceinline__ void trav_wide_step(Trav& tr, const TreeView& tv, con
     refs = *reinterpret_cast<const u32x4*>(base + (size_t)(at + 96u));
   }
   const RayBox& q = tr.q;
-  const float tn0 = max3_raw(fmaf(NX.x, q.rx, q.nx.x), fmaf(NY.x, q.ry, q.ny.x), max_raw(fmaf(NZ.x, q.rz, q.nz.x), tminf));
-  const float tn1 = max3_raw(fmaf(NX.y, q.rx, q.nx.x), fmaf(NY.y, q.ry, q.ny.x), max_raw(fmaf(NZ.y, q.rz, q.nz.x), tminf));
-  const float tn2 = max3_raw(fmaf(NX.z, q.rx, q.nx.x), fmaf(NY.z, q.ry, q.ny.x), max_raw(fmaf(NZ.z, q.rz, q.nz.x), tminf));
-  const float tn3 = max3_raw(fmaf(NX.w, q.rx, q.nx.x), fmaf(NY.w, q.ry, q.ny.x), max_raw(fmaf(NZ.w, q.rz, q.nz.x), tminf));
+  const float tn0 = max3_raw(fmaf(NX.x, q.rx, q.nx.x), fmaf(NY.x, q.ry, q.ny.x), fma_clamp(NZ.x, q.rz, q.nz.x));
+  const float tn1 = max3_raw(fmaf(NX.y, q.rx, q.nx.x), fmaf(NY.y, q.ry, q.ny.x), fma_clamp(NZ.y, q.rz, q.nz.x));
+  const float tn2 = max3_raw(fmaf(NX.z, q.rx, q.nx.x), fmaf(NY.z, q.ry, q.ny.x), fma_clamp(NZ.z, q.rz, q.nz.x));
+  const float tn3 = max3_raw(fmaf(NX.w, q.rx, q.nx.x), fmaf(NY.w, q.ry, q.ny.x), fma_clamp(NZ.w, q.rz, q.nz.x));
   const float tf0 = min3_raw(fmaf(FX.x, q.rx, q.nx.y), fmaf(FY.x, q.ry, q.ny.y), min_raw(fmaf(FZ.x, q.rz, q.nz.y), tr.tmaxf));
   const float tf1 = min3_raw(fmaf(FX.y, q.rx, q.nx.y), fmaf(FY.y, q.ry, q.ny.y), min_raw(fmaf(FZ.y, q.rz, q.nz.y), tr.tmaxf));
   const float tf2 = min3_raw(fmaf(FX.z, q.rx, q.nx.y), fmaf(FY.z, q.ry, q.ny.y), min_raw(fmaf(FZ.z, q.rz, q.nz.y), tr.tmaxf));
@@ -736,7 +779,7 @@ __device__ __forceinline__ void sphere_test(Trav& tr, const TreeView& tv, uint32
     if (t_min < t && t < tr.t_best) {
       tr.t_best = t;
       tr.best = (int)slot;
-      tr.tmaxf = f32_beyond(t);
+      tr.tmaxf = tau_beyond(tv.time, t);
     }
   }
 }
@@ -765,10 +808,9 @@ __device__ __forceinline__ void trav_leaf_step(Trav& tr, const TreeView& tv, Sta
 template <bool kAllLds, class StackPtr>
 __device__ __forceinline__ void trav_run(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride, double t_min, uint32_t& n_steps,
                                          uint32_t& n_tests) {
-  const float tminf = f32_below(t_min);
   while (tr.cur != kRefDone) {
     while (!(tr.cur & kRefLeaf)) {
-      trav_inner_step<kAllLds>(tr, tv, stack, stride, tminf);
+      trav_inner_step<kAllLds>(tr, tv, stack, stride);
       ++n_steps;
     }
     if (tr.cur != kRefDone) trav_leaf_step<kAllLds>(tr, tv, stack, stride, t_min, n_tests);
@@ -778,10 +820,9 @@ __device__ __forceinline__ void trav_run(Trav& tr, const TreeView& tv, StackPtr 
 // The same over the four-wide tree.
 __device__ __forceinline__ void trav_run_wide(Trav& tr, const TreeView& tv, const HybridStack& st, double t_min, uint32_t& n_steps,
                                               uint32_t& n_tests) {
-  const float tminf = f32_below(t_min);
   while (tr.cur != kRefDone) {
     while (!(tr.cur & kRefLeaf)) {
-      trav_wide_step(tr, tv, st, tminf);
+      trav_wide_step(tr, tv, st);
       ++n_steps;
     }
     if (tr.cur != kRefDone) trav_leaf_step<false>(tr, tv, st, 0u, t_min, n_tests);
@@ -877,8 +918,10 @@ struct LdsImage {
   lds_u32* stack_base;
 };
 
+// `t_min`: where the intervals of the kernel's queries start; `time_scale`: see TimeFrame (0: from the scene's extent).
 template <bool kAllLds, bool kWide = false>
-__device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const CameraDev* cam, float4* smem, uint32_t wg) {
+__device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const CameraDev* cam, float4* smem, uint32_t wg, double t_min,
+                                                float time_scale = 0.0f) {
   lds_double* lcam = (lds_double*)smem;
   lds_double* ltrig = lcam + CAM_DOUBLES;
   lds_float4* lnodes = (lds_float4*)(ltrig + 2 * kTrigEntries);
@@ -929,6 +972,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
   // a tree that is in LDS as a whole is walked by LDS addresses (see stage_node)
   im.tv.root = (kAllLds && !kWide && !(sc.root & kRefLeaf)) ? lds_node_address(lnodes, sc.root) : sc.root;
   im.tv.bound = sc.bound;
+  im.tv.time = time_frame(t_min, time_scale > 0.0f ? time_scale : time_scale_for(sc.bound));
   im.tv.single_leaves = sc.single_leaves != 0u;
   im.cam.p = lcam;
   im.trig.tab = ltrig;

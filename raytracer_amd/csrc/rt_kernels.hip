@@ -14,7 +14,7 @@ __global__ __launch_bounds__(kWorkgroup) void trace_batch_kernel(SceneDev sc, co
                                                                  double* __restrict__ t_out, double* __restrict__ normal,
                                                                  uint8_t* __restrict__ front, uint32_t* __restrict__ counts) {
   extern __shared__ float4 smem[];
-  const LdsImage im = stage_scene<kAllLds, kWide>(sc, nullptr, smem, kWorkgroup);
+  const LdsImage im = stage_scene<kAllLds, kWide>(sc, nullptr, smem, kWorkgroup, t_min);
   const TreeView& tv = im.tv;
   const uint32_t gtid = blockIdx.x * kWorkgroup + threadIdx.x;
   for (size_t i = (size_t)blockIdx.x * kWorkgroup + threadIdx.x; i < n; i += (size_t)gridDim.x * kWorkgroup) {
@@ -91,12 +91,12 @@ __global__ __launch_bounds__(256) void slab_batch_kernel(const float4* __restric
   D3 o = d3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
   D3 d = normalize(d3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
   const float4 lo = boxes[2 * i], hi = boxes[2 * i + 1];
-  RayBox q = ray_box(o, d, lo.w);
   double t_min = interval[2 * i], t_max = interval[2 * i + 1];
-  float tminf = f32_below(t_min);
-  float tmaxf = (t_max < 3.0e38) ? f32_above(t_max) : __builtin_inff();
+  // the ray's time frame starts at the interval's start; scaled for a scene of the box's own extent
+  const TimeFrame frame = time_frame(t_min, time_scale_for(lo.w));
+  RayBox q = ray_box(o, d, lo.w, frame);
   float tn;
-  hit[i] = box_test(q, f32x2{lo.x, hi.x}, f32x2{lo.y, hi.y}, f32x2{lo.z, hi.z}, tminf, tmaxf, tn) ? 1 : 0;
+  hit[i] = box_test(q, f32x2{lo.x, hi.x}, f32x2{lo.y, hi.y}, f32x2{lo.z, hi.z}, 0.0f, tau_above(frame, t_max), tn) ? 1 : 0;
 }
 
 // ----------------------------------------------------------- primary rays ----
@@ -169,7 +169,8 @@ __device__ __forceinline__ uint32_t count_mask(unsigned long long m) {
 template <bool kAllLds, bool kProf, bool kGStack, bool kSingle, bool kWide = false>
 __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  // 16 waves per CU: at most 128 VGPRs
   extern __shared__ float4 smem[];
-  const LdsImage im = stage_scene<kAllLds, kWide>(P.sc, &P.cam, smem, kWorkgroup);
+  const double t_min = 1e-3;  // src/camera.rs:102
+  const LdsImage im = stage_scene<kAllLds, kWide>(P.sc, &P.cam, smem, kWorkgroup, t_min, P.time_scale);
   const TreeView& tv = im.tv;
   // The lane's stack column is recomputed where it is used (one add), not kept in a register.
   auto stack_of_lane = [&]() {
@@ -189,8 +190,6 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
       return stack_origin(stack_of_lane());
   };
   const uint32_t lane = threadIdx.x & 63u;
-  const double t_min = 1e-3;  // src/camera.rs:102
-  const float tminf = f32_below(t_min);
   constexpr uint32_t kNoUnit = 0xffffffffu;
 
   // A unit of work is one pixel's samples of one chunk of the sample range.  A wave takes a batch
@@ -359,10 +358,10 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
             RTA_PROF(BLK_INNER)
             uint32_t steps;
             if constexpr (kWide) {
-              trav_wide_step(tr, tv, RTA_STACK, tminf);
+              trav_wide_step(tr, tv, RTA_STACK);
               steps = 1u;
             } else {
-              steps = trav_inner_pair<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
+              steps = trav_inner_pair<kAllLds>(tr, tv, RTA_STACK, stack_stride);
             }
             if (kProf) n_steps += steps;
           }
@@ -420,9 +419,9 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
         if (!(tr.cur & kRefLeaf)) {
           RTA_PROF(BLK_INNER)
           if constexpr (kWide)
-            trav_wide_step(tr, tv, RTA_STACK, tminf);
+            trav_wide_step(tr, tv, RTA_STACK);
           else
-            trav_inner_step<kAllLds>(tr, tv, RTA_STACK, stack_stride, tminf);
+            trav_inner_step<kAllLds>(tr, tv, RTA_STACK, stack_stride);
           if (kProf) ++n_steps;
         }
         RTA_T1(BLK_INNER)

@@ -63,6 +63,7 @@ struct RenderParams {
   uint32_t inner_min;  // a wave runs the inner-node block while at least this many of its lanes want it
   uint32_t leaf_min;   // inside a run of inner-node rounds the leaf block runs as soon as this many lanes wait at leaves
   uint32_t both_min;   // when a traversal block (inner or leaf) is due, the other one runs too if this many lanes want it
+  float time_scale;    // power of two that brings the times of the scene, seen from the camera, below 1 (0: from the scene's extent alone)
   double* out;
   unsigned long long* counters;  // see kRenderCounters
 };

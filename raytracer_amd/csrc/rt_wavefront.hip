@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void wf_generate_kernel(WfParams P) {
 template <bool kAllLds, bool kWide>
 __global__ __launch_bounds__(kWorkgroup) void wf_trace_kernel(WfParams P) {
   extern __shared__ float4 smem[];
-  const LdsImage im = stage_scene<kAllLds, kWide>(P.sc, nullptr, smem, kWorkgroup);
+  const LdsImage im = stage_scene<kAllLds, kWide>(P.sc, nullptr, smem, kWorkgroup, 1e-3);
   const TreeView& tv = im.tv;
   const uint32_t n = P.counts[0];
   const uint32_t gtid = blockIdx.x * kWorkgroup + threadIdx.x;
