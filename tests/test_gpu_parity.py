@@ -172,6 +172,32 @@ def test_trace_interval_arguments(world, oworld, rtiow):
         compare_hits(world.trace_batch(org, d, t_min, t_max), oworld.trace_batch(org, d, t_min, t_max))
 
 
+def test_trace_rays_from_far_outside_the_scene(world, oworld, rtiow):
+    # The node tests run in a time scaled so that the scene's own distances stay below 1, with the entry time cut off
+    # there: rays that start 10 to 100 scene sizes away arrive later than that, which may cost them visits, never a hit.
+    # (From that far the f64 sphere test itself loses digits -- |oc|^2 is 1e10 against r^2 = 0.04 -- so a ray that
+    # grazes a sphere within 1e-5 of its radius may be told apart differently by the two implementations.)
+    rng = np.random.default_rng(10)
+    spheres = rtiow[0]
+    n = 1 << 13
+    k = rng.integers(0, len(spheres), n)
+    aim = spheres["center"][k] + rng.uniform(-0.5, 0.5, (n, 3)) * np.minimum(spheres["radius"][k, None], 2.0)
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    far = 10.0 ** rng.uniform(4.3, 5.3, n)  # the scene's planes reach 2 000, the time scale covers 32 768
+    org = aim + u * far[:, None]
+    d = aim - org
+    for t_min, t_max in [(1e-3, np.inf), (1e-3, 1e5), (3e4, np.inf)]:
+        got, want = world.trace_batch(org, d, t_min, t_max), oworld.trace_batch(org, d, t_min, t_max)
+        gh, wh = got["prim"] >= 0, want["prim"] >= 0
+        assert (gh != wh).sum() <= 2, (gh != wh).sum()
+        both = gh & wh
+        assert both.mean() > 0.3
+        dt = np.abs(got["t"][both] - want["t"][both]) / want["t"][both]
+        assert dt.max() <= 1e-8, dt.max()
+        assert (got["prim"][both] != want["prim"][both]).mean() <= 0.01
+
+
 def test_slab_test_never_misses_where_reference_hits(oracle):
     rng = np.random.default_rng(10)
     n = 1 << 18
