@@ -8,12 +8,17 @@
 //
 // Parity status: the slab test, the AABB algebra and Sphere::aabb /
 // clipped_aabb are pinned by the reference's own unit tests
-// (src/aabb.rs:89-194, src/sphere.rs:83-117).  Sphere::hit, BVH::new,
-// BVH::hit, the three scatter functions, the camera and the integrator have
-// no tests or fixtures in the reference and the reference cannot be built
-// here (no Rust toolchain), so for those functions parity is UNPINNED: the
-// restatement is reviewable line against line and is exercised by analytic
-// known-answer tests only.
+// (src/aabb.rs:89-194, src/sphere.rs:83-117).  The camera, get_ray, the sky
+// branch and the recursion of ray_colour, Sphere::hit (on the ground sphere),
+// HitRecord::new, the Lambertian scatter and write_colour are pinned by the
+// example render the reference keeps in its repository (image.png): the sky
+// region byte for byte, the far ground by its mean colour
+// (tests/test_reference_image.py).  BVH::new, BVH::hit, the metal and
+// dielectric scatter functions and the lens sampler have no test, fixture or
+// output in the reference that reaches them, and the reference cannot be built
+// here (no Rust toolchain), so for those parity is UNPINNED: the restatement is
+// reviewable line against line and is exercised by analytic known-answer
+// tests only.
 //
 // Arithmetic rules taken from the reference's dependencies (glam 0.24.2,
 // rand 0.8.5; versions from Cargo.lock): DVec3 is three scalar f64; dot is

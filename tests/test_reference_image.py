@@ -1,0 +1,78 @@
+"""The one output of the reference itself that exists -- the example render in its repository (image.png, README.md:4)
+-- against the oracle and against the GPU path.  The image's scene was random, but two regions do not depend on the
+random spheres (tests/golden/make_reference_image_fixture.py says why): the sky above the horizon must come out the
+same byte for byte, up to one step where a sample mean sits on a byte boundary; the mean colour of the ground far
+outside the field of small spheres must agree within one step of 256.  Together they pin, against the reference's own
+numbers, Config::camera, get_ray, the sky branch and the recursion of ray_colour, Sphere::hit on the ground sphere,
+HitRecord::new, the Lambertian scatter with its unit-sphere sampler, and write_colour."""
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROWS, WIDTH = 150, 830
+
+
+@pytest.fixture(scope="module")
+def reference_rows():
+    f = np.load(os.path.join(HERE, "golden", "reference_image_rows.npz"))
+    assert int(f["width"]) == WIDTH and int(f["height"]) == 466 and f["rgb"].shape == (ROWS, WIDTH, 3)
+    return f["rgb"].astype(np.int64)
+
+
+def regions(camera, trace):
+    """Masks of the two regions from the closest hits of the rays through the pixel centres."""
+    jj, ii = np.meshgrid(np.arange(ROWS), np.arange(WIDTH), indexing="ij")
+    d = camera["pixel00_loc"] + ii[..., None] * camera["pixel_delta_u"] + jj[..., None] * camera["pixel_delta_v"] - camera["center"]
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    o = np.broadcast_to(camera["center"], d.shape).reshape(-1, 3)
+    hit = trace(o, d.reshape(-1, 3))
+    prim, t = hit["prim"].reshape(ROWS, WIDTH), hit["t"].reshape(ROWS, WIDTH)
+    with np.errstate(invalid="ignore"):
+        p = camera["center"] + np.where(np.isfinite(t), t, 0.0)[..., None] * d
+    # clear of the horizon by more than the lens can tilt a ray (the defocus disk is 0.05 wide at 10 units)
+    sky = (prim < 0) & (d[..., 1] > 0.02)
+    # the small spheres lie within |x|, |z| < 12 and below y = 0.4; sphere 0 is the ground
+    far_ground = (prim == 0) & ((np.abs(p[..., 0]) > 13.5) | (np.abs(p[..., 2]) > 13.5))
+    return sky, far_ground
+
+
+def check(rendered_bytes, reference_rows, sky, far_ground):
+    got = np.asarray(rendered_bytes).reshape(-1, WIDTH, 3)[:ROWS].astype(np.int64)
+    diff = got - reference_rows
+    assert sky.sum() > 5000 and far_ground.sum() > 8000
+    assert np.abs(diff[sky]).max() <= 1
+    assert (diff[sky] == 0).all(axis=-1).mean() >= 0.9
+    mean_diff = diff[far_ground].mean(axis=0)
+    assert np.abs(mean_diff).max() <= 1.0, mean_diff
+    return (diff[sky] == 0).all(axis=-1).mean(), mean_diff
+
+
+def camera_fields(cam):
+    return {k: getattr(cam, k) for k in ("center", "pixel00_loc", "pixel_delta_u", "pixel_delta_v")}
+
+
+def test_oracle_reproduces_the_reference_image(oracle, reference_rows):
+    spheres, materials = oracle.scene_rtiow(1)
+    scene = oracle.Scene(spheres, materials)
+    cfg = rt.config_rtiow(WIDTH, 32, 50).record().view(oracle.CONFIG_DTYPE)
+    _, cam = oracle.camera_derive(cfg)
+    sky, far_ground = regions(cam, lambda o, d: scene.trace_batch(o, d))
+    rgb, _ = scene.render(cfg, 2024, 0, 32, tile=(0, 0, WIDTH, ROWS), nthreads=os.cpu_count() or 1)
+    exact, mean_diff = check(oracle.quantise(rgb, 32), reference_rows, sky, far_ground)
+    print("oracle vs image.png: %.1f %% of %d sky pixels identical, far ground mean differs by %s of 256" % (100 * exact, sky.sum(), np.round(mean_diff, 2)))
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_the_reference_image(reference_rows):
+    spheres, materials = rt.scene_rtiow(1)
+    world = rt.BVH(spheres, materials)
+    cam = rt.config_rtiow(WIDTH, 256, 50).camera()
+    sky, far_ground = regions(camera_fields(cam), lambda o, d: world.trace_batch(o, d))
+    rgb, _ = cam.render_sum(world, seed=2024, spp_begin=0, spp_end=256, tile=(0, 0, WIDTH, ROWS))
+    exact, mean_diff = check(rt.quantise(rgb, 256), reference_rows, sky, far_ground)
+    print("GPU vs image.png: %.1f %% of %d sky pixels identical, far ground mean differs by %s of 256" % (100 * exact, sky.sum(), np.round(mean_diff, 2)))
+    world.close()
