@@ -10,11 +10,12 @@
 // clipped_aabb are pinned by the reference's own unit tests
 // (src/aabb.rs:89-194, src/sphere.rs:83-117).  The camera, get_ray, the sky
 // branch and the recursion of ray_colour, Sphere::hit (on the ground sphere),
-// HitRecord::new, the Lambertian scatter and write_colour are pinned by the
-// example render the reference keeps in its repository (image.png): the sky
-// region byte for byte, the far ground by its mean colour
-// (tests/test_reference_image.py).  BVH::new, BVH::hit, the metal and
-// dielectric scatter functions and the lens sampler have no test, fixture or
+// HitRecord::new, the Lambertian scatter, the Metal scatter without fuzz (with
+// vector::reflect) and write_colour are pinned by the example render the
+// reference keeps in its repository (image.png): the sky and the sky mirrored
+// in the large metal sphere byte for byte, the far ground by its mean colour
+// (tests/test_reference_image.py).  BVH::new, BVH::hit, the fuzz of the metal
+// scatter, the dielectric scatter and the lens sampler have no test, fixture or
 // output in the reference that reaches them, and the reference cannot be built
 // here (no Rust toolchain), so for those parity is UNPINNED: the restatement is
 // reviewable line against line and is exercised by analytic known-answer

@@ -1,14 +1,17 @@
 """The one output of the reference itself that exists -- the example render in its repository (image.png, README.md:4)
 -- against the oracle and against the GPU path.  The image's scene was random, but two regions do not depend on the
-random spheres (tests/golden/make_reference_image_fixture.py says why): the sky above the horizon must come out the
-same byte for byte, up to one step where a sample mean sits on a byte boundary; the mean colour of the ground far
-outside the field of small spheres must agree within one step of 256.  Together they pin, against the reference's own
-numbers, Config::camera, get_ray, the sky branch and the recursion of ray_colour, Sphere::hit on the ground sphere,
-HitRecord::new, the Lambertian scatter with its unit-sphere sampler, and write_colour."""
+random spheres (tests/golden/make_reference_image_fixture.py says why), and a third one follows from the three fixed
+spheres: the sky above the horizon must come out the same byte for byte, up to one step where a sample mean sits on a
+byte boundary; so must the part of the large metal sphere (fuzz 0) that mirrors nothing but sky; the mean colour of the
+ground far outside the field of small spheres must agree within one step of 256.  Together they pin, against the
+reference's own numbers, Config::camera, get_ray, the sky branch and the recursion of ray_colour, Sphere::hit (on the
+ground sphere and on a unit sphere: hit point and normal), HitRecord::new, the Metal scatter with vector::reflect, the
+Lambertian scatter with its unit-sphere sampler, and write_colour."""
 import os
 
 import numpy as np
 import pytest
+from scipy.ndimage import binary_erosion
 
 import raytracer_amd as rt
 
@@ -37,18 +40,28 @@ def regions(camera, trace):
     sky = (prim < 0) & (d[..., 1] > 0.02)
     # the small spheres lie within |x|, |z| < 12 and below y = 0.4; sphere 0 is the ground
     far_ground = (prim == 0) & ((np.abs(p[..., 0]) > 13.5) | (np.abs(p[..., 2]) > 13.5))
-    return sky, far_ground
+    # sphere 3 is the large metal sphere (src/main.rs:79-82: albedo (0.7, 0.6, 0.5), fuzz 0): where its mirror image of the
+    # pixel centre's ray leaves upwards and meets nothing (the small spheres end at y = 0.4, below every such ray)
+    n = hit["normal"].reshape(ROWS, WIDTH, 3)
+    mirrored = d - 2.0 * (d * n).sum(axis=-1, keepdims=True) * n
+    on_metal = prim == 3
+    second = trace(p[on_metal], mirrored[on_metal])
+    metal_sky = np.zeros((ROWS, WIDTH), dtype=bool)
+    metal_sky[on_metal] = (second["prim"] < 0) & (mirrored[on_metal][:, 1] > 0.05)
+    metal_sky = binary_erosion(metal_sky, iterations=3)  # whole pixel footprints (jitter, lens) inside the region
+    return sky, far_ground, metal_sky
 
 
-def check(rendered_bytes, reference_rows, sky, far_ground):
+def check(rendered_bytes, reference_rows, sky, far_ground, metal_sky):
     got = np.asarray(rendered_bytes).reshape(-1, WIDTH, 3)[:ROWS].astype(np.int64)
     diff = got - reference_rows
-    assert sky.sum() > 5000 and far_ground.sum() > 8000
-    assert np.abs(diff[sky]).max() <= 1
-    assert (diff[sky] == 0).all(axis=-1).mean() >= 0.9
+    assert sky.sum() > 5000 and far_ground.sum() > 8000 and metal_sky.sum() > 15000
+    for region in (sky, metal_sky):
+        assert np.abs(diff[region]).max() <= 1
+        assert (diff[region] == 0).all(axis=-1).mean() >= 0.9
     mean_diff = diff[far_ground].mean(axis=0)
     assert np.abs(mean_diff).max() <= 1.0, mean_diff
-    return (diff[sky] == 0).all(axis=-1).mean(), mean_diff
+    return (diff[sky] == 0).all(axis=-1).mean(), (diff[metal_sky] == 0).all(axis=-1).mean(), mean_diff
 
 
 def camera_fields(cam):
@@ -60,10 +73,11 @@ def test_oracle_reproduces_the_reference_image(oracle, reference_rows):
     scene = oracle.Scene(spheres, materials)
     cfg = rt.config_rtiow(WIDTH, 32, 50).record().view(oracle.CONFIG_DTYPE)
     _, cam = oracle.camera_derive(cfg)
-    sky, far_ground = regions(cam, lambda o, d: scene.trace_batch(o, d))
+    sky, far_ground, metal_sky = regions(cam, lambda o, d: scene.trace_batch(o, d, want_p=False))
     rgb, _ = scene.render(cfg, 2024, 0, 32, tile=(0, 0, WIDTH, ROWS), nthreads=os.cpu_count() or 1)
-    exact, mean_diff = check(oracle.quantise(rgb, 32), reference_rows, sky, far_ground)
-    print("oracle vs image.png: %.1f %% of %d sky pixels identical, far ground mean differs by %s of 256" % (100 * exact, sky.sum(), np.round(mean_diff, 2)))
+    exact, exact_metal, mean_diff = check(oracle.quantise(rgb, 32), reference_rows, sky, far_ground, metal_sky)
+    print("oracle vs image.png: %.1f %% of %d sky pixels and %.1f %% of %d mirrored-sky pixels identical, far ground mean differs by %s of 256"
+          % (100 * exact, sky.sum(), 100 * exact_metal, metal_sky.sum(), np.round(mean_diff, 2)))
 
 
 @pytest.mark.gpu
@@ -71,8 +85,9 @@ def test_gpu_reproduces_the_reference_image(reference_rows):
     spheres, materials = rt.scene_rtiow(1)
     world = rt.BVH(spheres, materials)
     cam = rt.config_rtiow(WIDTH, 256, 50).camera()
-    sky, far_ground = regions(camera_fields(cam), lambda o, d: world.trace_batch(o, d))
+    sky, far_ground, metal_sky = regions(camera_fields(cam), lambda o, d: world.trace_batch(o, d))
     rgb, _ = cam.render_sum(world, seed=2024, spp_begin=0, spp_end=256, tile=(0, 0, WIDTH, ROWS))
-    exact, mean_diff = check(rt.quantise(rgb, 256), reference_rows, sky, far_ground)
-    print("GPU vs image.png: %.1f %% of %d sky pixels identical, far ground mean differs by %s of 256" % (100 * exact, sky.sum(), np.round(mean_diff, 2)))
+    exact, exact_metal, mean_diff = check(rt.quantise(rgb, 256), reference_rows, sky, far_ground, metal_sky)
+    print("GPU vs image.png: %.1f %% of %d sky pixels and %.1f %% of %d mirrored-sky pixels identical, far ground mean differs by %s of 256"
+          % (100 * exact, sky.sum(), 100 * exact_metal, metal_sky.sum(), np.round(mean_diff, 2)))
     world.close()
