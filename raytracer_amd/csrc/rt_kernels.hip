@@ -349,12 +349,14 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
       // cursor, the stack and the closest hit.  A round runs the inner-node block (two steps per
       // lane) if inner_min lanes are at inner nodes and then the leaf block if leaf_min lanes are
       // at leaves; it ends when neither is the case.
-      uint32_t n_inner = count_lanes(!(tr.cur & kRefLeaf));
+      // (the lanes at inner nodes as a mask too: the block's execution mask is that mask, not a second compare)
+      unsigned long long m_inner = __ballot(!(tr.cur & kRefLeaf));
+      uint32_t n_inner = count_mask(m_inner);
       for (;;) {
         bool ran = false;
         if (n_inner >= P.inner_min) {
           RTA_T0()
-          if (!(tr.cur & kRefLeaf)) {
+          if (__builtin_amdgcn_inverse_ballot_w64(m_inner)) {
             RTA_PROF(BLK_INNER)
             uint32_t steps;
             if constexpr (kWide) {
@@ -379,7 +381,8 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           RTA_T1(BLK_LEAF)
           ran = true;
         }
-        n_inner = count_lanes(!(tr.cur & kRefLeaf));
+        m_inner = __ballot(!(tr.cur & kRefLeaf));
+        n_inner = count_mask(m_inner);
         if (!ran) break;
       }
       // Too few: run the block most lanes are waiting for.
