@@ -245,8 +245,7 @@ __device__ __forceinline__ void camera_ray(const Cam& cam, uint32_t width, bool 
 // the plane the ray enters through and added for the one it leaves through;
 // which of lo/hi that is depends on the sign of r, so the two constants are
 // stored as (c_lo, c_hi) and entry/exit are min/max of the two products.
-// An axis whose reciprocal is not a usable f32 number (direction component
-// ~ 0) constrains nothing, which is conservative.
+// The reciprocal of a direction component ~ 0 is cut to +-1e18 (see ray_box_axis), which keeps the test conservative.
 #define RTA_U24 5.9604644775390625e-08f /* 2^-24 */
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -260,11 +259,21 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // (covered by the pad: 2 * t0 more half-ulps); scaling by a power of two does not round.
 struct TimeFrame {
   float t0, scale;
+  float t0s;     // t0 * scale: the interval's start in scaled time
+  float pad_t0;  // the share of the subtraction of t0s in the pad of a plane constant: 2^-24 * 2 * |t0s|
 };
+// A wave-uniform float kept in a scalar register (the scalar unit has no float arithmetic: left alone, the compiler
+// works such values out per lane and holds them in vector registers).
+__device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ TimeFrame time_frame(double t_min, float scale) {
   float f = (float)t_min;
   if ((double)f > t_min) f = nextafterf(f, -__builtin_inff());  // the largest f32 <= t_min
-  return TimeFrame{f, scale};
+  const float t0s = f * scale;
+  return TimeFrame{f, scale, t0s, RTA_U24 * 2.0f * fabsf(t0s)};
+}
+// The same frame for every lane of the wave: its numbers in scalar registers.
+__device__ __forceinline__ TimeFrame uniform_frame(TimeFrame tf) {
+  return TimeFrame{uniform_f32(tf.t0), uniform_f32(tf.scale), uniform_f32(tf.t0s), uniform_f32(tf.pad_t0)};
 }
 // A power of two that brings the times a ray can spend in a scene of this extent (and 16 times more) below 1.
 __device__ __forceinline__ float time_scale_for(float bound) {
@@ -286,28 +295,29 @@ struct RayBox {
   f32x2 nx, ny, nz;  // (c_near, c_far) per axis: the same two constants by the order the ray meets the planes
 };
 
-__device__ __forceinline__ void ray_box_axis(double o, double d, float bound, TimeFrame tf, float& rf, f32x2& c2, f32x2& s2) {
-  float df = (float)d;
-  float r1 = __builtin_amdgcn_rcpf(df);
-  float r = r1 * tf.scale;  // everything below is in scaled time (a power of two: no rounding)
-  float of = (float)o;
-  float orf = of * r;
-  const float t0s = tf.t0 * tf.scale;
-  float e = RTA_U24 * (6.0f * bound * fabsf(r) + 12.0f * fabsf(orf) + 2.0f * fabsf(t0s));
-  bool ok = fabsf(r1) <= 1e18f;  // false for inf and NaN too
-  float cn = -orf - (e + t0s), cf = -orf + (e - t0s);
-  bool neg = r < 0.0f;
-  rf = ok ? r : 0.0f;
-  c2 = ok ? (neg ? f32x2{cf, cn} : f32x2{cn, cf}) : f32x2{-__builtin_inff(), __builtin_inff()};
-  s2 = ok ? f32x2{cn, cf} : f32x2{-__builtin_inff(), __builtin_inff()};
+// `pad_bound` = 2^-24 * 6 * B (see above).  The reciprocal is cut to +-1e18: a ray that (almost) does not move along the axis
+// then gets plane times of +-(distance to the plane) * 1e18 * scale, far outside the scene's times on the side the plane
+// lies, unless the origin is within rounding of the plane, and that is what the pad (which grows with |r|) covers.  No
+// infinity or NaN comes out of the constants this way, and nothing needs to be singled out.
+__device__ __forceinline__ void ray_box_axis(double o, double d, float pad_bound, TimeFrame tf, float& rf, f32x2& c2, f32x2& s2) {
+  const float r1 = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf((float)d), -1e18f, 1e18f);
+  const float r = r1 * tf.scale;  // everything below is in scaled time (a power of two: no rounding)
+  const float orf = (float)o * r;
+  const float e = fmaf(pad_bound, fabsf(r), fmaf(RTA_U24 * 12.0f, fabsf(orf), tf.pad_t0));
+  const float cn = -orf - (e + tf.t0s), cf = -orf + (e - tf.t0s);
+  rf = r;
+  c2 = r < 0.0f ? f32x2{cf, cn} : f32x2{cn, cf};
+  s2 = f32x2{cn, cf};
 }
-__device__ __forceinline__ RayBox ray_box(D3 o, D3 d, float bound, TimeFrame tf) {
+__device__ __forceinline__ RayBox ray_box(D3 o, D3 d, float pad_bound, TimeFrame tf) {
   RayBox q;
-  ray_box_axis(o.x, d.x, bound, tf, q.rx, q.cx, q.nx);
-  ray_box_axis(o.y, d.y, bound, tf, q.ry, q.cy, q.ny);
-  ray_box_axis(o.z, d.z, bound, tf, q.rz, q.cz, q.nz);
+  ray_box_axis(o.x, d.x, pad_bound, tf, q.rx, q.cx, q.nx);
+  ray_box_axis(o.y, d.y, pad_bound, tf, q.ry, q.cy, q.ny);
+  ray_box_axis(o.z, d.z, pad_bound, tf, q.rz, q.cz, q.nz);
   return q;
 }
+// 2^-24 * 6 * B for a tree whose plane coordinates are at most B in size
+__device__ __forceinline__ float pad_for_bound(float bound) { return RTA_U24 * 6.0f * bound; }
 __device__ __forceinline__ float f32_below(double v) {  // largest f32 <= v
   float f = (float)v;
   return ((double)f > v) ? nextafterf(f, -__builtin_inff()) : f;
@@ -323,7 +333,7 @@ __device__ __forceinline__ float f32_beyond(double v) { return __uint_as_float(_
 // shifted by one multiply-add (one rounding), and moved one step up again.
 __device__ __forceinline__ float tau_beyond(const TimeFrame& tf, double t) {
   const float t_up = __uint_as_float(__float_as_uint((float)t) + 1u);
-  return __uint_as_float(__float_as_uint(fmaf(t_up, tf.scale, -tf.t0 * tf.scale)) + 1u);
+  return __uint_as_float(__float_as_uint(fmaf(t_up, tf.scale, -tf.t0s)) + 1u);
 }
 // One box given as (lo, hi) pairs per axis: does the ray cross it within [tminf, tmaxf] (in the ray's time frame)?
 __device__ __forceinline__ bool box_test(const RayBox& q, f32x2 bx, f32x2 by, f32x2 bz, float tminf, float tmaxf, float& tn) {
@@ -414,6 +424,7 @@ struct TreeView {
   uint32_t n_lds, n_sph_lds, n_aux_lds, n_mat_lds;
   uint32_t root;
   float bound;
+  float pad_bound;     // pad_for_bound(bound)
   TimeFrame time;      // the frame the node tests run in: the start of the queries' interval and the scene's time scale
   bool single_leaves;  // every leaf holds exactly one sphere
 };
@@ -451,7 +462,7 @@ __device__ __forceinline__ void stage_node(lds_float4* lnodes, uint32_t i, f32x4
   p[5] = f32x4{q2.y, q2.w, q2.x, q2.z};
   p[6] = q3;
 }
-// Node i from LDS for a ray whose byte offsets into the node are off = (x, y, z copy to read).
+// Node i from LDS for a ray that reads copy off / 16 of each axis (off = 0 or 16).
 template <bool kScaled>
 __device__ __forceinline__ void fetch_node_lds(const TreeView& tv, uint32_t i, uint32_t offx, uint32_t offy, uint32_t offz, f32x4& X, f32x4& Y,
                                                f32x4& Z, f32x2& refs) {
@@ -459,8 +470,8 @@ __device__ __forceinline__ void fetch_node_lds(const TreeView& tv, uint32_t i, u
   // kScaled: i is the node's LDS address itself
   lds_char* node = kScaled ? (lds_char*)(uintptr_t)i : (lds_char*)tv.lnodes + __umul24(i, kLdsNodeQuads * 16u);
   X = *(lds_float4*)(node + offx);
-  Y = *(lds_float4*)(node + offy);
-  Z = *(lds_float4*)(node + offz);
+  Y = *(lds_float4*)(node + 32u + offy);
+  Z = *(lds_float4*)(node + 64u + offz);
   refs = *(lds_float2*)(node + 96u);  // only the two references: no dead destination registers
 }
 __device__ __forceinline__ void fetch_node_global(const TreeView& tv, uint32_t i, f32x4& q0, f32x4& q1, f32x4& q2, f32x2& refs) {
@@ -501,7 +512,7 @@ struct Trav {
   RayBox q;
   double t_best;
   float tmaxf;
-  uint32_t offx, offy, offz;  // byte offset, inside a node staged in LDS, of the copy of each axis to read
+  uint32_t offx, offy, offz;  // per axis, which of the two copies in a node staged in LDS to read: byte offset 0 or 16 within the axis
   uint32_t cur, sp;  // sp: where the stack's free slot is (see stack_slot)
   uint32_t tos;  // the top of the stack lives here; `sp` entries below it are in LDS
   int best;
@@ -512,19 +523,14 @@ template <bool kWide = false>
 __device__ __forceinline__ void trav_begin(Trav& tr, const TreeView& tv, D3 o, D3 d, double t_max, uint32_t sp0 = 0u) {
   tr.o = o;
   tr.d = d;
-  tr.q = ray_box(o, d, tv.bound, tv.time);
+  tr.q = ray_box(o, d, tv.pad_bound, tv.time);
   tr.t_best = t_max;
   tr.tmaxf = tau_above(tv.time, t_max);
-  // The copy must match the sign the node test sees, which is that of the f32 reciprocal.
-  if (kWide) {  // four-wide nodes: per axis, the byte offset of the word of planes met first
-    tr.offx = tr.q.rx < 0.0f ? 16u : 0u;
-    tr.offy = tr.q.ry < 0.0f ? 16u : 0u;
-    tr.offz = tr.q.rz < 0.0f ? 16u : 0u;
-  } else {
-    tr.offx = tr.q.rx < 0.0f ? 16u : 0u;
-    tr.offy = tr.q.ry < 0.0f ? 48u : 32u;
-    tr.offz = tr.q.rz < 0.0f ? 80u : 64u;
-  }
+  // The copy must match the sign the node test sees, which is that of the f32 reciprocal (never a zero: it is the
+  // reciprocal of a number, cut to +-1e18): 16 where the ray travels down the axis, from the sign bit.
+  tr.offx = (__float_as_uint(tr.q.rx) >> 27) & 16u;
+  tr.offy = (__float_as_uint(tr.q.ry) >> 27) & 16u;
+  tr.offz = (__float_as_uint(tr.q.rz) >> 27) & 16u;
   tr.cur = tv.root;
   tr.sp = sp0;
   tr.tos = kRefDone;  // popping the bottom entry ends the traversal
@@ -972,7 +978,8 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
   // a tree that is in LDS as a whole is walked by LDS addresses (see stage_node)
   im.tv.root = (kAllLds && !kWide && !(sc.root & kRefLeaf)) ? lds_node_address(lnodes, sc.root) : sc.root;
   im.tv.bound = sc.bound;
-  im.tv.time = time_frame(t_min, time_scale > 0.0f ? time_scale : time_scale_for(sc.bound));
+  im.tv.pad_bound = uniform_f32(pad_for_bound(sc.bound));
+  im.tv.time = uniform_frame(time_frame(t_min, time_scale > 0.0f ? time_scale : time_scale_for(sc.bound)));
   im.tv.single_leaves = sc.single_leaves != 0u;
   im.cam.p = lcam;
   im.trig.tab = ltrig;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void slab_batch_kernel(const float4* __restric
   double t_min = interval[2 * i], t_max = interval[2 * i + 1];
   // the ray's time frame starts at the interval's start; scaled for a scene of the box's own extent
   const TimeFrame frame = time_frame(t_min, time_scale_for(lo.w));
-  RayBox q = ray_box(o, d, lo.w, frame);
+  RayBox q = ray_box(o, d, pad_for_bound(lo.w), frame);
   float tn;
   hit[i] = box_test(q, f32x2{lo.x, hi.x}, f32x2{lo.y, hi.y}, f32x2{lo.z, hi.z}, 0.0f, tau_above(frame, t_max), tn) ? 1 : 0;
 }
