@@ -37,8 +37,8 @@ __device__ __forceinline__ void philox4x32_render(uint32_t k0, uint32_t k1, uint
 }
 // 53 random bits scaled by 2^-53: uniform in [0,1) like rand's Standard f64.
 __device__ __forceinline__ double unit_from_bits(uint32_t lo, uint32_t hi) {
-  unsigned long long v = ((unsigned long long)hi << 32) | lo;
-  return (double)(v >> 11) * (1.0 / 9007199254740992.0);
+  // (the top 53 of the 64 bits) * 2^-53 = hi * 2^-32 + (lo without its low 11 bits) * 2^-64: every step is exact
+  return fma((double)hi, 1.0 / 4294967296.0, (double)(lo & 0xfffff800u) * (1.0 / 18446744073709551616.0));
 }
 // Two uniforms of 53 bits from one block: what a scatter event draws.
 __device__ __forceinline__ void philox_pair(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t slot, uint32_t domain,
@@ -68,6 +68,10 @@ __device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b
 __device__ __forceinline__ D3 operator*(double s, D3 a) { return {s * a.x, s * a.y, s * a.z}; }
 __device__ __forceinline__ D3 operator*(D3 a, D3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 __device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// v with its sign bit flipped where `mask` (0 or 0x80000000) has it set
+__device__ __forceinline__ double flip_sign(double v, uint32_t mask) {
+  return __hiloint2double(__double2hiint(v) ^ (int)mask, __double2loint(v));
+}
 
 // A double constant that is materialised where it is used (two scalar moves).
 // Without this the compiler hoists the polynomial coefficients below out of
@@ -176,7 +180,7 @@ __device__ __forceinline__ void sincos_2pi(double u, double& s, double& c, TrigT
 template <class Trig = TrigSeries>
 __device__ __forceinline__ D3 unit_from_uniforms(double u0, double u1, Trig trig = Trig{}) {
   double z = 1.0 - 2.0 * u0;
-  double rxy = sqrt_plain(fmax(0.0, 1.0 - z * z));
+  double rxy = sqrt_plain(1.0 - z * z);  // (a rounding below zero is lifted like a zero)
   double s, c;
   sincos_2pi(u1, s, c, trig);
   return d3(rxy * c, rxy * s, z);
@@ -855,7 +859,8 @@ __device__ __forceinline__ Hit make_hit(const TreeView& tv, int slot, D3 o, D3 d
   h.p = d3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
   D3 n = ax.x * d3(h.p.x - s0.x, h.p.y - s0.y, h.p.z - s1.x);
   h.front = dot(d, n) < 0.0;
-  h.normal = h.front ? n : d3(-n.x, -n.y, -n.z);
+  const uint32_t flip = h.front ? 0u : 0x80000000u;  // the normal against the ray: one select and three sign flips
+  h.normal = d3(flip_sign(n.x, flip), flip_sign(n.y, flip), flip_sign(n.z, flip));
   unsigned long long bits = (unsigned long long)__double_as_longlong(ax.y);
   h.material = (uint32_t)bits;
   h.prim = (uint32_t)(bits >> 32);
@@ -866,7 +871,8 @@ __device__ __forceinline__ Hit make_hit(const TreeView& tv, int slot, D3 o, D3 d
 // incoming ray, `mat` the material index with its type in the top 2 bits.
 // Material record (32 bytes): Lambertian/Metal (albedo.x, albedo.y)(albedo.z, fuzz);
 // Dielectric (ir, 1/ir)(r0, -) with r0 = ((1-ir)/(1+ir))^2, which is the same
-// number for ir and 1/ir.  Returns false where the reference returns None.
+// number for ir and 1/ir.  Returns false where the reference returns None (out_dir is then a direction nobody follows:
+// the lanes of a wave go through the normalisation together anyway).
 template <bool kAllLds, class Trig = TrigSeries>
 __device__ __forceinline__ bool scatter(const TreeView& tv, uint32_t mat, D3 d, const Hit& h, double u0, double u1, D3& attenuation,
                                         D3& out_dir, Trig trig = Trig{}) {
@@ -881,6 +887,7 @@ __device__ __forceinline__ bool scatter(const TreeView& tv, uint32_t mat, D3 d, 
     m1 = p[1];
   }
   D3 dir;
+  bool scattered = true;
   if (type == 2u) {  // Dielectric
     attenuation = d3(1.0, 1.0, 1.0);
     double ratio = h.front ? m0.y : m0.x;  // ir^-1 entering, ir leaving (src/material.rs:52)
@@ -904,14 +911,17 @@ __device__ __forceinline__ bool scatter(const TreeView& tv, uint32_t mat, D3 d, 
     D3 unit = unit_from_uniforms(u0, u1, trig);
     if (type == 0u) {  // Lambertian
       dir = h.normal + unit;
-      if (fabs(dir.x) <= 1e-6 && fabs(dir.y) <= 1e-6 && fabs(dir.z) <= 1e-6) dir = h.normal;  // near_zero, src/vector.rs:52-54
+      const bool near_zero = fabs(dir.x) <= 1e-6 && fabs(dir.y) <= 1e-6 && fabs(dir.z) <= 1e-6;  // src/vector.rs:52-54
+      if (__builtin_amdgcn_ballot_w64(near_zero)) {  // (a branch of the wave: practically never taken)
+        if (near_zero) dir = h.normal;
+      }
     } else {  // Metal
       dir = (d - (2.0 * dot(d, h.normal)) * h.normal) + m1.y * unit;
-      if (dot(dir, h.normal) <= 0.0) return false;
+      scattered = !(dot(dir, h.normal) <= 0.0);
     }
   }
   out_dir = normalize(dir);  // Ray::new, src/ray.rs:16-23
-  return true;
+  return scattered;
 }
 
 // ------------------------------------------------------------ LDS image ----

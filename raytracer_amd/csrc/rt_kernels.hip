@@ -247,19 +247,18 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
         if (tr.cur == kRefDone && tr.best >= 0) {  // a ray that missed everything is finished by the camera block
           RTA_PROF(BLK_SHADE)
           ++n_rays;
-          bool ended = true;
           const Hit h = make_hit<kAllLds>(tv, tr.best, tr.o, tr.d, tr.t_best);
           double u0, u1;
           philox_pair(P.seed_lo, P.seed_hi, RTA_J * P.cam.width + RTA_I, s, P.cam.max_depth - depth_left, DOM_SCATTER, u0, u1);
           D3 att, nd;
-          if (scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd, im.trig)) {  // None = absorbed, src/camera.rs:108-110
-            thr = thr * att;
-            if (--depth_left != 0) {  // depth exhausted: the path contributes nothing (src/camera.rs:99-101)
-              trav_begin<kWide>(tr, tv, h.p, nd, __builtin_inf(), empty_stack());  // HitRecord::ray, src/hit.rs:29-31
-              ended = false;
-            }
-          }
-          if (ended) {
+          // None = absorbed (src/camera.rs:108-110); depth exhausted: the path contributes nothing (src/camera.rs:99-101).
+          // Everything below is written whether the path goes on or not (what a finished path leaves behind is
+          // overwritten when the lane's next sample starts), so the new ray is worked out where it is kept.
+          const bool scattered = scatter<kAllLds>(tv, h.material, tr.d, h, u0, u1, att, nd, im.trig);
+          thr = thr * att;
+          --depth_left;
+          trav_begin<kWide>(tr, tv, h.p, nd, __builtin_inf(), empty_stack());  // HitRecord::ray, src/hit.rs:29-31
+          if (!scattered || depth_left == 0) {
             ++s;
             tr.cur = kRefCamera;
           }
