@@ -277,7 +277,8 @@ int rt_render_device_noalloc(const rt_scene* scene, const rt_config* cfg, uint64
  * pixels in four chunks of the sample range instead of 8x8 pixels in one, when the number of chunks allows) -- none of these changes which
  * samples are rendered; "force_global_stack" (scenes created while it is 1 keep
  * their traversal stacks in global memory, the path trees deeper than 35 levels
- * take); "force_staged_sum" (rt_render_multi adds sample-split frames through copies to the first
+ * take); "first_leaf" (1, the default: in scenes created while it is 1, a one-sphere leaf directly under the root of the
+ * host-built tree is tested when a query starts and taken out of the walk; closest hits are the same); "force_staged_sum" (rt_render_multi adds sample-split frames through copies to the first
  * device even where peers can read each other).  inner_min and leaf_min must be whole numbers in 1 .. 64,
  * both_min in 0 .. 64; other values are refused.  The knobs are process-wide atomics: a render call reads them
  * once when it starts.  With RT_PROFILE_BLOCKS set in the environment, rt_render* runs the

@@ -101,6 +101,7 @@ std::atomic<uint32_t> g_both_min{8};
 std::atomic<uint32_t> g_leaf_min{10};
 // Samples of one pixel that make a unit of work (the sample range is cut into chunks of about this size).
 std::atomic<uint32_t> g_chunk_spp{64};
+std::atomic<uint32_t> g_first_leaf{1};  // 0: keep a leaf under the root inside the walk (for measurements)
 std::atomic<uint32_t> g_quad_tiles{1};
 // Fewest units of work a call is cut into (32 per lane of the chip).
 std::atomic<uint64_t> g_target_units{1u << 25};
@@ -371,6 +372,21 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
     for (const DevNode& nd : flat.nodes) single = single && one(nd.ref0) && one(nd.ref1);
   }
   dev.single_leaves = single ? 1u : 0u;
+  // A one-sphere leaf directly under the root of the host's two-wide tree (the reference scene's ground sphere: as
+  // large as the scene, split off first by the surface-area heuristic) is tested when a query starts and the walk
+  // begins at its sibling: the closest hit is the same, found with one node step and one leaf round fewer per ray.
+  dev.first_leaf = kRefNone;
+  if (!wide && !on_device && g_first_leaf.load() && !(dev.root & kRefLeaf) && dev.root < flat.nodes.size()) {
+    auto one_sphere = [](uint32_t ref) { return (ref & kRefLeaf) && ref != kRefNone && ((ref >> 24) & 0x7fu) == 1u; };
+    const DevNode& top = flat.nodes[dev.root];
+    if (one_sphere(top.ref0)) {
+      dev.first_leaf = top.ref0 & 0x00ffffffu;
+      dev.root = top.ref1;
+    } else if (one_sphere(top.ref1)) {
+      dev.first_leaf = top.ref1 & 0x00ffffffu;
+      dev.root = top.ref0;
+    }
+  }
   *on_device_out = on_device;
   *depth_out = tree_depth;
   *n_dev_nodes_out = n_final_nodes;
@@ -1431,6 +1447,10 @@ int rt_debug_set(const char* name, double value) {
     if (key == "target_units") {
       if (!(value >= 1.0 && value <= 1e12)) return fail(RT_ERR_INVALID, "rt_debug_set: target_units must be in 1 .. 1e12");
       g_target_units.store((uint64_t)value);
+      return RT_OK;
+    }
+    if (key == "first_leaf") {  // takes effect for scenes created afterwards
+      g_first_leaf.store(value != 0.0 ? 1u : 0u);
       return RT_OK;
     }
     if (key == "quad_tiles") {

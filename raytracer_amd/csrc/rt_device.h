@@ -427,6 +427,7 @@ struct TreeView {
   lds_double2* lmat;  // LDS copy of materials [0, n_mat_lds)
   uint32_t n_lds, n_sph_lds, n_aux_lds, n_mat_lds;
   uint32_t root;
+  uint32_t first_leaf;  // see SceneDev
   float bound;
   float pad_bound;     // pad_for_bound(bound)
   TimeFrame time;      // the frame the node tests run in: the start of the queries' interval and the scene's time scale
@@ -793,6 +794,15 @@ __device__ __forceinline__ void sphere_test(Trav& tr, const TreeView& tv, uint32
     }
   }
 }
+// The sphere that stands outside the tree (TreeView::first_leaf), tested when a query starts.  In the reference's tree
+// it is a leaf under the root whose box the query's origin lies in, so it is the first thing the walk would test anyway
+// (src/bvh.rs:50-84); here that costs no node step and no round of the leaf block.  Returns the number of tests made.
+template <bool kAllLds>
+__device__ __forceinline__ uint32_t trav_first(Trav& tr, const TreeView& tv, double t_min) {
+  if (tv.first_leaf == kRefDone) return 0u;
+  sphere_test<kAllLds>(tr, tv, tv.first_leaf, t_min);
+  return 1u;
+}
 // One leaf: each of its spheres in stored order.  Trees whose leaves all hold one sphere (what
 // both builders make of spheres that do not coincide) take the branch without the loop.
 // kSingle: the caller knows at compile time that the tree is of that kind (the loop is then not even
@@ -987,6 +997,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
   im.tv.n_mat_lds = sc.n_materials_lds;
   // a tree that is in LDS as a whole is walked by LDS addresses (see stage_node)
   im.tv.root = (kAllLds && !kWide && !(sc.root & kRefLeaf)) ? lds_node_address(lnodes, sc.root) : sc.root;
+  im.tv.first_leaf = sc.first_leaf;
   im.tv.bound = sc.bound;
   im.tv.pad_bound = uniform_f32(pad_for_bound(sc.bound));
   im.tv.time = uniform_frame(time_frame(t_min, time_scale > 0.0f ? time_scale : time_scale_for(sc.bound)));

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kWorkgroup) void trace_batch_kernel(SceneDev sc, co
     uint32_t sp0 = 0u;
     if constexpr (!kWide) sp0 = kGStack ? 0u : stack_origin(im.stack_base + threadIdx.x);
     trav_begin<kWide>(tr, tv, o, d, t_max, sp0);
-    uint32_t n_steps = 0, n_tests = 0;
+    uint32_t n_steps = 0, n_tests = trav_first<kAllLds>(tr, tv, t_min);
     if constexpr (kWide)
       trav_run_wide(tr, tv, HybridStack{im.stack_base + threadIdx.x, sc.gstack + gtid, sc.lds_stack, sc.gstack_stride}, t_min, n_steps, n_tests);
     else if constexpr (kGStack)
@@ -258,6 +258,10 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           thr = thr * att;
           --depth_left;
           trav_begin<kWide>(tr, tv, h.p, nd, __builtin_inf(), empty_stack());  // HitRecord::ray, src/hit.rs:29-31
+          {
+            const uint32_t first = trav_first<kAllLds>(tr, tv, t_min);
+            if (kProf) n_tests += first;
+          }
           if (!scattered || depth_left == 0) {
             ++s;
             tr.cur = kRefCamera;
@@ -336,6 +340,10 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
             thr = d3(1.0, 1.0, 1.0);
             depth_left = P.cam.max_depth;
             trav_begin<kWide>(tr, tv, o, d, __builtin_inf(), empty_stack());
+            {
+            const uint32_t first = trav_first<kAllLds>(tr, tv, t_min);
+            if (kProf) n_tests += first;
+          }
           }
         }
       }

@@ -31,6 +31,8 @@ struct SceneDev {
   uint32_t gstack_stride;   // threads of the launch
   uint32_t root;            // ref of the root: inner node 0, a leaf ref, or 0xffffffff for an empty scene
   uint32_t single_leaves;   // 1: every leaf holds exactly one sphere (the leaf test then needs no loop)
+  uint32_t first_leaf;      // slot of a sphere that every query tests before it walks the tree from `root`, or 0xffffffff: a one-sphere leaf
+                            // directly under the tree's root (a ground sphere as large as the scene) is taken out of the walk this way
   float bound;              // largest |coordinate| of any box plane in the tree
   // Four-wide tree (scenes that do not fit in LDS): nodes are 64-byte WideNode records, n_nodes_lds of them staged
   // in LDS; the first lds_stack entries of a lane's stack live in LDS, the other stack_cap - lds_stack in gstack.

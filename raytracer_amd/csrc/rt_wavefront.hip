@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kWorkgroup) void wf_trace_kernel(WfParams P) {
     uint32_t sp0 = 0u;
     if constexpr (!kWide) sp0 = stack_origin(im.stack_base + threadIdx.x);
     trav_begin<kWide>(tr, tv, o, d, __builtin_inf(), sp0);
-    uint32_t n_steps = 0, n_tests = 0;
+    uint32_t n_steps = 0, n_tests = trav_first<kAllLds>(tr, tv, 1e-3);
     if constexpr (kWide)
       trav_run_wide(tr, tv, HybridStack{im.stack_base + threadIdx.x, P.sc.gstack + gtid, P.sc.lds_stack, P.sc.gstack_stride}, 1e-3, n_steps, n_tests);
     else

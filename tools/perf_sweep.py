@@ -30,6 +30,7 @@ if a.config:
 else:
     spheres, materials = rt.scene_rtiow(1)
     cfg = rt.config_rtiow(a.width, a.spp, 50)
+SCENE_KNOBS = ("first_leaf", "force_wide", "force_global_stack")  # read when a scene is created: the scene is rebuilt per value
 world = rt.BVH(spheres, materials)
 cam = cfg.camera()
 frame = torch.zeros((cam.image_height, a.width, 3), dtype=torch.float64, device="cuda")
@@ -37,6 +38,9 @@ best = {}
 for r in range(a.rounds):  # interleaved rounds in one process
     for v in a.values:
         rt._lib.check(L.rt_debug_set(a.name.encode(), C.c_double(v)))
+        if a.name in SCENE_KNOBS:
+            world.close()
+            world = rt.BVH(spheres, materials)
         frame.zero_()
         torch.cuda.synchronize()
         st = cam.render_device(world, frame.data_ptr(), seed=12345, spp_begin=0, spp_end=a.spp)
