@@ -436,9 +436,9 @@ FlatBvh flatten_bvh(const HostBvh& bvh, const rt_sphere* spheres, size_t n) {
   return f;
 }
 
-WideBvh collapse_wide(const DevNode* nodes, size_t n_nodes) {
+WideBvh collapse_wide(const DevNode* nodes, size_t n_nodes, uint32_t root) {
   WideBvh w;
-  if (n_nodes == 0) return w;
+  if (n_nodes == 0 || root >= n_nodes) return w;
   struct Child {
     float lo[3], hi[3];
     uint32_t ref;
@@ -460,7 +460,7 @@ WideBvh collapse_wide(const DevNode* nodes, size_t n_nodes) {
     return dx * dy + dy * dz + dz * dx;
   };
   // breadth-first over the wide nodes; each is rooted at a two-wide inner node
-  std::vector<uint32_t> root_of{0};
+  std::vector<uint32_t> root_of{root};
   std::vector<uint32_t> level{1};
   w.nodes.reserve(n_nodes / 2 + 1);
   double bound = 0.0;

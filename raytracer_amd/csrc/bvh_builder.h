@@ -89,8 +89,8 @@ struct WideBvh {
   uint32_t stack_entries = 0;   // entries a traversal can have outstanding, at most
   float bound = 0.0f;           // largest |coordinate| of any reconstructed plane
 };
-// Collapses a two-wide device tree (root = inner node 0) into the four-wide form: a node takes its two
+// Collapses the two-wide device tree below inner node `root` into the four-wide form: a node takes its two
 // children and then, twice, replaces the inner child of largest surface area by that child's own children.
-WideBvh collapse_wide(const DevNode* nodes, size_t n_nodes);
+WideBvh collapse_wide(const DevNode* nodes, size_t n_nodes, uint32_t root = 0);
 
 }  // namespace rta

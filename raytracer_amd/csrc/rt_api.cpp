@@ -290,6 +290,23 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
     }
   }
 
+  // A one-sphere leaf directly under the root of the host's two-wide tree (the reference scene's ground sphere: as
+  // large as the scene, split off first by the surface-area heuristic) is tested when a query starts and the walk
+  // begins at its sibling: the closest hit is the same, found with one node step and one leaf round fewer per ray.
+  uint32_t first_leaf = kRefNone, walk_root = on_device ? tree.root : flat.root;
+  if (!on_device && g_first_leaf.load() && !(flat.root & kRefLeaf) && flat.root < flat.nodes.size()) {
+    auto one_sphere = [](uint32_t ref) { return (ref & kRefLeaf) && ref != kRefNone && ((ref >> 24) & 0x7fu) == 1u; };
+    const DevNode& top = flat.nodes[flat.root];
+    if (one_sphere(top.ref0)) {
+      first_leaf = top.ref0 & 0x00ffffffu;
+      walk_root = top.ref1;
+    } else if (one_sphere(top.ref1)) {
+      first_leaf = top.ref1 & 0x00ffffffu;
+      walk_root = top.ref0;
+    }
+  }
+  const bool wide_peel = first_leaf != kRefNone && !(walk_root & kRefLeaf);  // the four-wide tree is then collapsed from the sibling
+
   // A scene that fits in LDS as a whole is walked through its two-wide tree; any other through the four-wide
   // tree with quantised boxes (half the bytes per ray), collapsed here from the two-wide nodes.
   const bool fits = n_nodes_lds == n_dev_nodes && n_sph_lds == n && n_aux_lds == n && n_mat_lds == n_used;
@@ -310,7 +327,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
       wide_stack_entries = 3 * levels + 1;  // at most three children set aside per level
       wide_bound = tree.bound;
     } else {
-      if (wide_cache->nodes.empty()) *wide_cache = collapse_wide(flat.nodes.data(), n_dev_nodes);
+      if (wide_cache->nodes.empty()) *wide_cache = collapse_wide(flat.nodes.data(), n_dev_nodes, wide_peel ? walk_root : flat.root);
       n_final_nodes = wide_cache->nodes.size();
       wide_stack_entries = wide_cache->stack_entries;
       wide_bound = std::fmax(wide_cache->bound, flat.bound);
@@ -372,21 +389,8 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
     for (const DevNode& nd : flat.nodes) single = single && one(nd.ref0) && one(nd.ref1);
   }
   dev.single_leaves = single ? 1u : 0u;
-  // A one-sphere leaf directly under the root of the host's two-wide tree (the reference scene's ground sphere: as
-  // large as the scene, split off first by the surface-area heuristic) is tested when a query starts and the walk
-  // begins at its sibling: the closest hit is the same, found with one node step and one leaf round fewer per ray.
-  dev.first_leaf = kRefNone;
-  if (!wide && !on_device && g_first_leaf.load() && !(dev.root & kRefLeaf) && dev.root < flat.nodes.size()) {
-    auto one_sphere = [](uint32_t ref) { return (ref & kRefLeaf) && ref != kRefNone && ((ref >> 24) & 0x7fu) == 1u; };
-    const DevNode& top = flat.nodes[dev.root];
-    if (one_sphere(top.ref0)) {
-      dev.first_leaf = top.ref0 & 0x00ffffffu;
-      dev.root = top.ref1;
-    } else if (one_sphere(top.ref1)) {
-      dev.first_leaf = top.ref1 & 0x00ffffffu;
-      dev.root = top.ref0;
-    }
-  }
+  dev.first_leaf = wide && !wide_peel ? kRefNone : first_leaf;
+  if (!wide && first_leaf != kRefNone) dev.root = walk_root;
   *on_device_out = on_device;
   *depth_out = tree_depth;
   *n_dev_nodes_out = n_final_nodes;
