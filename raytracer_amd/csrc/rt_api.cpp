@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -232,6 +233,91 @@ int make_camera_dev(const rt_config* cfg, CameraDev* cam, const char* who) {
   return RT_OK;
 }
 
+
+// Looks in the top levels of the host's two-wide tree for a one-sphere leaf whose box has at least half the surface
+// area of the whole tree's, and takes it out: its sibling takes its parent's place and the boxes recorded for the
+// ancestors shrink to what is left below them.  *first_leaf = the sphere's slot, *walk_root = where the walk starts;
+// *edited = the node array with those changes (left empty when the leaf hangs directly under the root: no node changes,
+// the walk just starts at the sibling).  Nothing is written when there is no such leaf.
+void take_out_first_leaf(const FlatBvh& flat, std::vector<DevNode>* edited, uint32_t* first_leaf, uint32_t* walk_root) {
+  if ((flat.root & kRefLeaf) || flat.root >= flat.nodes.size()) return;
+  struct Box {
+    float lo[3], hi[3];
+  };
+  auto child_box = [](const DevNode& d, int c) {
+    return Box{{d.x[2 * c], d.y[2 * c], d.z[2 * c]}, {d.x[2 * c + 1], d.y[2 * c + 1], d.z[2 * c + 1]}};
+  };
+  auto set_child_box = [](DevNode& d, int c, const Box& b) {
+    d.x[2 * c] = b.lo[0], d.x[2 * c + 1] = b.hi[0];
+    d.y[2 * c] = b.lo[1], d.y[2 * c + 1] = b.hi[1];
+    d.z[2 * c] = b.lo[2], d.z[2 * c + 1] = b.hi[2];
+  };
+  auto merged = [](const Box& a, const Box& b) {
+    Box m;
+    for (int k = 0; k < 3; ++k) m.lo[k] = std::min(a.lo[k], b.lo[k]), m.hi[k] = std::max(a.hi[k], b.hi[k]);
+    return m;
+  };
+  auto area = [](const Box& b) {
+    const double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  };
+  auto one_sphere = [](uint32_t ref) { return (ref & kRefLeaf) && ref != kRefNone && ((ref >> 24) & 0x7fu) == 1u; };
+  const DevNode& top = flat.nodes[flat.root];
+  const double whole = area(merged(child_box(top, 0), child_box(top, 1)));
+  // depth-first over the top four levels; `path` holds (node, child slot taken) from the root down
+  constexpr int kLevels = 4;
+  struct Step {
+    uint32_t node;
+    int slot;
+  };
+  std::vector<Step> path, found;
+  int found_slot = -1;
+  std::function<bool(uint32_t)> visit = [&](uint32_t n) {
+    const DevNode& d = flat.nodes[n];
+    for (int c = 0; c < 2; ++c) {
+      const uint32_t ref = c == 0 ? d.ref0 : d.ref1;
+      if (one_sphere(ref) && area(child_box(d, c)) >= 0.5 * whole) {
+        found = path;
+        found.push_back(Step{n, c});
+        found_slot = c;
+        return true;
+      }
+    }
+    if ((int)path.size() + 1 >= kLevels) return false;
+    for (int c = 0; c < 2; ++c) {
+      const uint32_t ref = c == 0 ? d.ref0 : d.ref1;
+      if (!(ref & kRefLeaf) && ref < flat.nodes.size()) {
+        path.push_back(Step{n, c});
+        const bool hit = visit(ref);
+        path.pop_back();
+        if (hit) return true;
+      }
+    }
+    return false;
+  };
+  if (!visit(flat.root)) return;
+  const Step parent = found.back();
+  const DevNode& P = flat.nodes[parent.node];
+  const uint32_t leaf_ref = found_slot == 0 ? P.ref0 : P.ref1, sibling_ref = found_slot == 0 ? P.ref1 : P.ref0;
+  *first_leaf = leaf_ref & 0x00ffffffu;
+  if (found.size() == 1) {  // directly under the root
+    *walk_root = sibling_ref;
+    return;
+  }
+  *edited = flat.nodes;
+  std::vector<DevNode>& nodes = *edited;
+  // the grandparent's slot for the parent takes the sibling, with the sibling's box
+  const Step grand = found[found.size() - 2];
+  (grand.slot == 0 ? nodes[grand.node].ref0 : nodes[grand.node].ref1) = sibling_ref;
+  set_child_box(nodes[grand.node], grand.slot, child_box(P, 1 - found_slot));
+  // further up, the box recorded for the child on the path is the union of what that child now holds
+  for (size_t k = found.size() - 2; k-- > 0;) {
+    const DevNode& below = nodes[found[k + 1].node];
+    set_child_box(nodes[found[k].node], found[k].slot, merged(child_box(below, 0), child_box(below, 1)));
+  }
+  *walk_root = flat.root;
+}
+
 // ------------------------------------------------------------ scene set-up ----
 // Uploads one copy of the scene to the current device (or builds the tree there) and plans its LDS image.
 int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, size_t n_used, const std::vector<double>& mats,
@@ -290,22 +376,15 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
     }
   }
 
-  // A one-sphere leaf directly under the root of the host's two-wide tree (the reference scene's ground sphere: as
-  // large as the scene, split off first by the surface-area heuristic) is tested when a query starts and the walk
-  // begins at its sibling: the closest hit is the same, found with one node step and one leaf round fewer per ray.
+  // A sphere as large as the scene (the reference scene's ground) is a one-sphere leaf near the top of the host's tree:
+  // its box holds every ray's origin, so every walk tests it first, and it inflates the boxes of its ancestors to the
+  // whole scene.  Such a leaf is taken out of the tree the device walks (take_out_first_leaf) and tested when a query
+  // starts instead: the closest hit is the same, found with a node step and a leaf round fewer per ray.
   uint32_t first_leaf = kRefNone, walk_root = on_device ? tree.root : flat.root;
-  if (!on_device && g_first_leaf.load() && !(flat.root & kRefLeaf) && flat.root < flat.nodes.size()) {
-    auto one_sphere = [](uint32_t ref) { return (ref & kRefLeaf) && ref != kRefNone && ((ref >> 24) & 0x7fu) == 1u; };
-    const DevNode& top = flat.nodes[flat.root];
-    if (one_sphere(top.ref0)) {
-      first_leaf = top.ref0 & 0x00ffffffu;
-      walk_root = top.ref1;
-    } else if (one_sphere(top.ref1)) {
-      first_leaf = top.ref1 & 0x00ffffffu;
-      walk_root = top.ref0;
-    }
-  }
-  const bool wide_peel = first_leaf != kRefNone && !(walk_root & kRefLeaf);  // the four-wide tree is then collapsed from the sibling
+  std::vector<DevNode> edited;  // the host tree's nodes with the leaf taken out, if that changed any node
+  if (!on_device && g_first_leaf.load()) take_out_first_leaf(flat, &edited, &first_leaf, &walk_root);
+  const DevNode* host_nodes = on_device ? nullptr : (edited.empty() ? flat.nodes.data() : edited.data());
+  const bool wide_peel = first_leaf != kRefNone && !(walk_root & kRefLeaf);  // else the four-wide tree keeps the leaf
 
   // A scene that fits in LDS as a whole is walked through its two-wide tree; any other through the four-wide
   // tree with quantised boxes (half the bytes per ray), collapsed here from the two-wide nodes.
@@ -327,7 +406,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
       wide_stack_entries = 3 * levels + 1;  // at most three children set aside per level
       wide_bound = tree.bound;
     } else {
-      if (wide_cache->nodes.empty()) *wide_cache = collapse_wide(flat.nodes.data(), n_dev_nodes, wide_peel ? walk_root : flat.root);
+      if (wide_cache->nodes.empty()) *wide_cache = collapse_wide(wide_peel ? host_nodes : flat.nodes.data(), n_dev_nodes, wide_peel ? walk_root : flat.root);
       n_final_nodes = wide_cache->nodes.size();
       wide_stack_entries = wide_cache->stack_entries;
       wide_bound = std::fmax(wide_cache->bound, flat.bound);
@@ -353,7 +432,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
     }
   } else if (!on_device) {
     RT_HIP(hipMalloc(&rp.d_nodes, node_bytes ? node_bytes : 64));
-    if (node_bytes) RT_HIP(hipMemcpy(rp.d_nodes, flat.nodes.data(), node_bytes, hipMemcpyHostToDevice));
+    if (node_bytes) RT_HIP(hipMemcpy(rp.d_nodes, host_nodes, node_bytes, hipMemcpyHostToDevice));
   }
   if (!on_device) {
     RT_HIP(hipMalloc(&rp.d_spheres, sph_bytes ? sph_bytes : 32));

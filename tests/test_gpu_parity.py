@@ -649,16 +649,18 @@ def test_frame_does_not_depend_on_scheduling(world):
 
 
 def test_ground_sphere_outside_the_walk_changes_nothing(rtiow):
-    # By default a one-sphere leaf directly under the root (the ground sphere) is tested when a query starts and the
-    # walk begins at its sibling.  Closest hits and frames must be bit for bit those of the walk that includes it, on
-    # the two-wide tree in LDS and on the four-wide tree of a scene that overflows it, for any interval of the query.
+    # By default a one-sphere leaf as large as the scene directly under the root (the ground sphere) is tested when a query starts and the
+    # walk begins at its sibling; one found a few levels down is cut out of the tree.  Closest hits and frames must be
+    # bit for bit those of the walk that includes it, on the two-wide tree in LDS and on the four-wide tree of scenes that
+    # overflow it, for any interval of the query.
     import ctypes as C
 
     L = rt._lib.lib()
     field = rt.scene_field(5, 20000, 0.3, 0.4, 0.3)
+    deep = rt.scene_field(3, 600000, 0.15, 0.15)  # the ground's leaf hangs two levels below the root here: nodes are rewritten
     try:
         for (spheres, materials), cfg in ((rtiow, rt.config_rtiow(image_width=96, samples_per_pixel=8, max_depth=50)),
-                                          (field, rt.config_field(20000, 96, 8, 50))):
+                                          (field, rt.config_field(20000, 96, 8, 50)), (deep, rt.config_field(600000, 96, 4, 50))):
             results = []
             for flag in (0.0, 1.0):
                 rt._lib.check(L.rt_debug_set(b"first_leaf", C.c_double(flag)))
