@@ -234,13 +234,14 @@ int make_camera_dev(const rt_config* cfg, CameraDev* cam, const char* who) {
 }
 
 
-// Looks in the top levels of the host's two-wide tree for a one-sphere leaf whose box has at least half the surface
+// Looks in the top levels of a two-wide tree (nodes in breadth-first order) for a one-sphere leaf whose box has at least half the surface
 // area of the whole tree's, and takes it out: its sibling takes its parent's place and the boxes recorded for the
 // ancestors shrink to what is left below them.  *first_leaf = the sphere's slot, *walk_root = where the walk starts;
 // *edited = the node array with those changes (left empty when the leaf hangs directly under the root: no node changes,
 // the walk just starts at the sibling).  Nothing is written when there is no such leaf.
-void take_out_first_leaf(const FlatBvh& flat, std::vector<DevNode>* edited, uint32_t* first_leaf, uint32_t* walk_root) {
-  if ((flat.root & kRefLeaf) || flat.root >= flat.nodes.size()) return;
+void take_out_first_leaf(const DevNode* tree_nodes, size_t n_nodes, uint32_t root, std::vector<DevNode>* edited, uint32_t* first_leaf,
+                         uint32_t* walk_root) {
+  if ((root & kRefLeaf) || root >= n_nodes) return;
   struct Box {
     float lo[3], hi[3];
   };
@@ -262,7 +263,7 @@ void take_out_first_leaf(const FlatBvh& flat, std::vector<DevNode>* edited, uint
     return dx * dy + dy * dz + dz * dx;
   };
   auto one_sphere = [](uint32_t ref) { return (ref & kRefLeaf) && ref != kRefNone && ((ref >> 24) & 0x7fu) == 1u; };
-  const DevNode& top = flat.nodes[flat.root];
+  const DevNode& top = tree_nodes[root];
   const double whole = area(merged(child_box(top, 0), child_box(top, 1)));
   // depth-first over the top four levels; `path` holds (node, child slot taken) from the root down
   constexpr int kLevels = 4;
@@ -273,7 +274,7 @@ void take_out_first_leaf(const FlatBvh& flat, std::vector<DevNode>* edited, uint
   std::vector<Step> path, found;
   int found_slot = -1;
   std::function<bool(uint32_t)> visit = [&](uint32_t n) {
-    const DevNode& d = flat.nodes[n];
+    const DevNode& d = tree_nodes[n];
     for (int c = 0; c < 2; ++c) {
       const uint32_t ref = c == 0 ? d.ref0 : d.ref1;
       if (one_sphere(ref) && area(child_box(d, c)) >= 0.5 * whole) {
@@ -286,7 +287,7 @@ void take_out_first_leaf(const FlatBvh& flat, std::vector<DevNode>* edited, uint
     if ((int)path.size() + 1 >= kLevels) return false;
     for (int c = 0; c < 2; ++c) {
       const uint32_t ref = c == 0 ? d.ref0 : d.ref1;
-      if (!(ref & kRefLeaf) && ref < flat.nodes.size()) {
+      if (!(ref & kRefLeaf) && ref < n_nodes) {
         path.push_back(Step{n, c});
         const bool hit = visit(ref);
         path.pop_back();
@@ -295,16 +296,16 @@ void take_out_first_leaf(const FlatBvh& flat, std::vector<DevNode>* edited, uint
     }
     return false;
   };
-  if (!visit(flat.root)) return;
+  if (!visit(root)) return;
   const Step parent = found.back();
-  const DevNode& P = flat.nodes[parent.node];
+  const DevNode& P = tree_nodes[parent.node];
   const uint32_t leaf_ref = found_slot == 0 ? P.ref0 : P.ref1, sibling_ref = found_slot == 0 ? P.ref1 : P.ref0;
   *first_leaf = leaf_ref & 0x00ffffffu;
   if (found.size() == 1) {  // directly under the root
     *walk_root = sibling_ref;
     return;
   }
-  *edited = flat.nodes;
+  edited->assign(tree_nodes, tree_nodes + n_nodes);
   std::vector<DevNode>& nodes = *edited;
   // the grandparent's slot for the parent takes the sibling, with the sibling's box
   const Step grand = found[found.size() - 2];
@@ -315,7 +316,7 @@ void take_out_first_leaf(const FlatBvh& flat, std::vector<DevNode>* edited, uint
     const DevNode& below = nodes[found[k + 1].node];
     set_child_box(nodes[found[k].node], found[k].slot, merged(child_box(below, 0), child_box(below, 1)));
   }
-  *walk_root = flat.root;
+  *walk_root = root;
 }
 
 // ------------------------------------------------------------ scene set-up ----
@@ -382,7 +383,24 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   // starts instead: the closest hit is the same, found with a node step and a leaf round fewer per ray.
   uint32_t first_leaf = kRefNone, walk_root = on_device ? tree.root : flat.root;
   std::vector<DevNode> edited;  // the host tree's nodes with the leaf taken out, if that changed any node
-  if (!on_device && g_first_leaf.load()) take_out_first_leaf(flat, &edited, &first_leaf, &walk_root);
+  if (g_first_leaf.load() && !on_device) {
+    take_out_first_leaf(flat.nodes.data(), flat.nodes.size(), flat.root, &edited, &first_leaf, &walk_root);
+  } else if (g_first_leaf.load() && tree.n_nodes > 1) {
+    // the device builder's tree: its top four levels (breadth-first: the first 15 nodes at most) are looked at and
+    // rewritten here; a leaf directly under the root is dropped by copying its sibling's node over the root's
+    std::vector<DevNode> top(std::min<size_t>(tree.n_nodes, 15)), changed;
+    RT_HIP(hipMemcpy(top.data(), rp.d_nodes, top.size() * sizeof(DevNode), hipMemcpyDeviceToHost));
+    uint32_t slot = kRefNone, start = tree.root;
+    take_out_first_leaf(top.data(), top.size(), tree.root, &changed, &slot, &start);
+    if (slot != kRefNone && changed.empty() && !(start & kRefLeaf) && start < top.size()) {
+      changed = top;
+      changed[tree.root] = top[start];
+    }
+    if (slot != kRefNone && !changed.empty()) {
+      RT_HIP(hipMemcpy(rp.d_nodes, changed.data(), changed.size() * sizeof(DevNode), hipMemcpyHostToDevice));
+      first_leaf = slot;
+    }
+  }
   const DevNode* host_nodes = on_device ? nullptr : (edited.empty() ? flat.nodes.data() : edited.data());
   const bool wide_peel = first_leaf != kRefNone && !(walk_root & kRefLeaf);  // else the four-wide tree keeps the leaf
 

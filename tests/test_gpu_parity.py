@@ -662,20 +662,22 @@ def test_ground_sphere_outside_the_walk_changes_nothing(rtiow):
         for (spheres, materials), cfg in ((rtiow, rt.config_rtiow(image_width=96, samples_per_pixel=8, max_depth=50)),
                                           (field, rt.config_field(20000, 96, 8, 50)), (deep, rt.config_field(600000, 96, 4, 50))):
             results = []
-            for flag in (0.0, 1.0):
+            for flag, builder in ((0.0, 0), (1.0, 0), (1.0, 1)):  # (the last: the device-built tree, rewritten on the device)
                 rt._lib.check(L.rt_debug_set(b"first_leaf", C.c_double(flag)))
-                w = rt.BVH(spheres, materials)
+                w = rt.BVH(spheres, materials, builder=builder)
                 org, d = _secondary_rays(np.asarray(spheres)[1:2000], np.random.default_rng(3), 1 << 14)
                 grid = np.stack(np.meshgrid(np.linspace(20.3, 40.7, 8), [5.0], np.linspace(20.3, 40.7, 8)), -1).reshape(-1, 3)
                 up = grid, np.tile([0.0, -1.0, 0.0], (64, 1))  # straight down, between the small spheres onto the ground
                 results.append((w.trace_batch(org, d), w.trace_batch(org, d, t_min=0.5, t_max=3.0), w.trace_batch(*up),
                                 cfg.camera().render_sum(w, seed=5)))
                 w.close()
-            for a, b in zip(results[0][:3], results[1][:3]):
-                assert np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["t"], b["t"]) and np.array_equal(a["normal"], b["normal"])
+            for other in results[1:]:
+                for a, b in zip(results[0][:3], other[:3]):
+                    assert np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["t"], b["t"]) and np.array_equal(a["normal"], b["normal"])
             ground = int(np.argmax(np.asarray(spheres)["radius"]))
             assert (results[1][2]["prim"] == ground).any() and (results[1][0]["prim"] == ground).any()  # the ground is among the hits
-            assert np.array_equal(results[0][3][0], results[1][3][0]) and results[0][3][1]["rays"] == results[1][3][1]["rays"]
+            for other in results[1:]:
+                assert np.array_equal(results[0][3][0], other[3][0]) and results[0][3][1]["rays"] == other[3][1]["rays"]
     finally:
         rt._lib.check(L.rt_debug_set(b"first_leaf", C.c_double(1.0)))
 

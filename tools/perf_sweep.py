@@ -17,6 +17,7 @@ ap.add_argument("values", nargs="+", type=float)
 ap.add_argument("--spp", type=int, default=100)
 ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--builder", type=int, default=0, help="0: host SAH, 1: device LBVH")
 ap.add_argument("--config", default=None, help="c3, c4 or c5 of tools/run_configs.py instead of the reference scene (--width and --spp still apply)")
 a = ap.parse_args()
 
@@ -31,7 +32,7 @@ else:
     spheres, materials = rt.scene_rtiow(1)
     cfg = rt.config_rtiow(a.width, a.spp, 50)
 SCENE_KNOBS = ("first_leaf", "force_wide", "force_global_stack")  # read when a scene is created: the scene is rebuilt per value
-world = rt.BVH(spheres, materials)
+world = rt.BVH(spheres, materials, builder=a.builder)
 cam = cfg.camera()
 frame = torch.zeros((cam.image_height, a.width, 3), dtype=torch.float64, device="cuda")
 best = {}
@@ -40,7 +41,7 @@ for r in range(a.rounds):  # interleaved rounds in one process
         rt._lib.check(L.rt_debug_set(a.name.encode(), C.c_double(v)))
         if a.name in SCENE_KNOBS:
             world.close()
-            world = rt.BVH(spheres, materials)
+            world = rt.BVH(spheres, materials, builder=a.builder)
         frame.zero_()
         torch.cuda.synchronize()
         st = cam.render_device(world, frame.data_ptr(), seed=12345, spp_begin=0, spp_end=a.spp)
