@@ -657,22 +657,31 @@ __device__ __forceinline__ void node_apply(Trav& tr, const NodeChoice& c, StackP
   tr.sp += c.both ? 4u * stride : 0u;
   tr.tos = c.both ? c.far : tr.tos;
 }
-template <bool kAllLds, class StackPtr>
-__device__ __forceinline__ uint32_t trav_inner_pair(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride) {
-  const NodeData na = node_fetch<kAllLds>(tr, tv, tr.cur);
-  const NodeChoice ca = node_choose<kAllLds>(tr, na);
-  const bool go = !(ca.next & kRefLeaf);
-  NodeData nb;
-  if (go) nb = node_fetch<kAllLds>(tr, tv, ca.next);
-  node_apply(tr, ca, stack, stride);
-  tr.cur = ca.next;
-  if (go) {
-    const NodeChoice cb = node_choose<kAllLds>(tr, nb);
-    node_apply(tr, cb, stack, stride);
-    tr.cur = cb.next;
-    return 2u;
+// Up to kLeft node steps in a row for a lane that stays on inner nodes, the next node's fetch issued before the
+// stack work of the current step.  Returns the number of steps made.
+template <bool kAllLds, int kLeft, class StackPtr>
+__device__ __forceinline__ uint32_t inner_chain(Trav& tr, const TreeView& tv, const NodeData& n, StackPtr stack, uint32_t stride) {
+  const NodeChoice c = node_choose<kAllLds>(tr, n);
+  if constexpr (kLeft > 1) {
+    const bool go = !(c.next & kRefLeaf);
+    NodeData m;
+    if (go) m = node_fetch<kAllLds>(tr, tv, c.next);
+    node_apply(tr, c, stack, stride);
+    tr.cur = c.next;
+    if (go) return 1u + inner_chain<kAllLds, kLeft - 1>(tr, tv, m, stack, stride);
+    return 1u;
+  } else {
+    node_apply(tr, c, stack, stride);
+    tr.cur = c.next;
+    return 1u;
   }
-  return 1u;
+}
+// Node steps per round of the inner-node block (measured on the reference scene: 3 is 2 % faster than 2, 4 is 3 % slower, 5 is 1 % slower than 3).
+constexpr int kInnerSteps = 3;
+template <bool kAllLds, class StackPtr>
+__device__ __forceinline__ uint32_t trav_inner_steps(Trav& tr, const TreeView& tv, StackPtr stack, uint32_t stride) {
+  const NodeData n = node_fetch<kAllLds>(tr, tv, tr.cur);
+  return inner_chain<kAllLds, kInnerSteps>(tr, tv, n, stack, stride);
 }
 
 // ------------------------------------------------------- four-wide nodes ----

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
     bool finished = false;
     for (;;) {
       // Traversal rounds while enough lanes want them: the innermost loop, which only moves the
-      // cursor, the stack and the closest hit.  A round runs the inner-node block (two steps per
+      // cursor, the stack and the closest hit.  A round runs the inner-node block (up to three steps per
       // lane) if inner_min lanes are at inner nodes and then the leaf block if leaf_min lanes are
       // at leaves; it ends when neither is the case.
       // (the lanes at inner nodes as a mask too: the block's execution mask is that mask, not a second compare)
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
               trav_wide_step(tr, tv, RTA_STACK);
               steps = 1u;
             } else {
-              steps = trav_inner_pair<kAllLds>(tr, tv, RTA_STACK, stack_stride);
+              steps = trav_inner_steps<kAllLds>(tr, tv, RTA_STACK, stack_stride);
             }
             if (kProf) n_steps += steps;
           }
