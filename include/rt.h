@@ -286,6 +286,15 @@ int rt_render_device_noalloc(const rt_scene* scene, const rt_config* cfg, uint64
  * mean active lanes and cycles to stderr (slower; results unchanged). */
 int rt_debug_set(const char* name, double value);
 
+/* Test hook, host only (no GPU call): the rewrite that scene creation applies to the device's copy of a two-wide tree.
+ * `nodes`: n_nodes records of 64 bytes in breadth-first order -- f32 x[4], y[4], z[4] = (lo, hi) of child 0 then of
+ * child 1 per axis, u32 ref0, ref1, split axis, 0; a ref is a node index, or a leaf: bit 31 | sphere count << 24 |
+ * first slot.  Looks in the top four levels below `root` for a one-sphere leaf whose box has at least half the surface
+ * area of the tree's and takes it out (see "first_leaf" above): *first_leaf = its slot (0xffffffff: none found),
+ * *walk_root = where the walk starts, nodes_out = the nodes with the leaf's sibling in its parent's place and the
+ * ancestors' boxes shrunk (a copy of `nodes` when nothing changes).  No counterpart in the reference. */
+int rt_debug_take_out_first_leaf(const void* nodes, size_t n_nodes, uint32_t root, void* nodes_out, uint32_t* first_leaf, uint32_t* walk_root);
+
 /* Measurement harness, not a product path (no rt_render* entry point calls it): the same samples of the whole
  * frame rendered by a wavefront pipeline -- one kernel per stage (generate, trace, shade, resolve) with ray queues
  * in device memory, rays that go on packed with wave ballots -- so that its profile can be laid next to the

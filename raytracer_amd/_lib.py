@@ -95,6 +95,7 @@ EXPORTS = [
     "rt_partition",
     "rt_render_multi",
     "rt_debug_set",
+    "rt_debug_take_out_first_leaf",
     "rt_experiment_wavefront_device",
     "rt_quantise",
     "rt_write_ppm",

@@ -1504,6 +1504,19 @@ int rt_render_multi(const rt_scene* sc_, const rt_config* cfg, uint64_t seed, ui
   });
 }
 
+int rt_debug_take_out_first_leaf(const void* nodes, size_t n_nodes, uint32_t root, void* nodes_out, uint32_t* first_leaf, uint32_t* walk_root) {
+  return guarded("rt_debug_take_out_first_leaf", [&]() -> int {
+    if ((!nodes && n_nodes) || !nodes_out || !first_leaf || !walk_root) return fail(RT_ERR_INVALID, "rt_debug_take_out_first_leaf: null argument");
+    const DevNode* in = static_cast<const DevNode*>(nodes);
+    std::vector<DevNode> edited;
+    *first_leaf = kRefNone;
+    *walk_root = root;
+    take_out_first_leaf(in, n_nodes, root, &edited, first_leaf, walk_root);
+    if (n_nodes) std::memcpy(nodes_out, edited.empty() ? in : edited.data(), n_nodes * sizeof(DevNode));
+    return RT_OK;
+  });
+}
+
 int rt_debug_set(const char* name, double value) {
   return guarded("rt_debug_set", [&]() -> int {
     if (!name) return fail(RT_ERR_INVALID, "rt_debug_set: name is null");

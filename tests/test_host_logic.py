@@ -313,3 +313,81 @@ def test_rust_ffi_declarations_match_the_header():
     header = open(os.path.join(root, "include", "rt.h")).read()
     for cname, value in re.findall(r"pub const (RT_\w+): u32 = (\d+);", src):
         assert re.search(r"\b%s = %s\b" % (cname, value), header), cname
+
+
+# ---- the scene-sized leaf taken out of the device's copy of the tree (host logic of scene creation) ----
+DEV_NODE = np.dtype([("x", "<f4", 4), ("y", "<f4", 4), ("z", "<f4", 4), ("ref0", "<u4"), ("ref1", "<u4"), ("axis", "<u4"), ("pad", "<u4")])
+LEAF, NONE = 0x80000000, 0xFFFFFFFF
+
+
+def _leaf(slot, count=1):
+    return LEAF | (count << 24) | slot
+
+
+def _node(box0, ref0, box1, ref1):
+    n = np.zeros((), dtype=DEV_NODE)
+    for axis, name in enumerate("xyz"):
+        n[name] = (box0[0][axis], box0[1][axis], box1[0][axis], box1[1][axis])
+    n["ref0"], n["ref1"] = ref0, ref1
+    return n
+
+
+def _take_out(nodes, root=0):
+    import ctypes as C
+
+    nodes = np.ascontiguousarray(nodes, dtype=DEV_NODE)
+    out = np.zeros_like(nodes)
+    first, start = C.c_uint32(), C.c_uint32()
+    rc = rt._lib.lib().rt_debug_take_out_first_leaf(nodes.ctypes.data_as(C.c_void_p), C.c_size_t(len(nodes)), C.c_uint32(root),
+                                                    out.ctypes.data_as(C.c_void_p), C.byref(first), C.byref(start))
+    assert rc == 0
+    return out, first.value, start.value
+
+
+def _child_box(n, c):
+    return tuple(float(n[a][2 * c]) for a in "xyz"), tuple(float(n[a][2 * c + 1]) for a in "xyz")
+
+
+BIG = ((-1000.0, -2000.0, -1000.0), (1000.0, 0.0, 1000.0))  # the box of a ground sphere
+A, B, C_, D = ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), ((2.0, 0.0, 0.0), (3.0, 1.0, 1.0)), ((5.0, 0.0, 4.0), (6.0, 1.0, 5.0)), ((8.0, 0.0, 0.0), (9.0, 2.0, 1.0))
+
+
+def _union(p, q):
+    return tuple(min(a, b) for a, b in zip(p[0], q[0])), tuple(max(a, b) for a, b in zip(p[1], q[1]))
+
+
+def test_take_out_leaf_directly_under_the_root():
+    # root = (ground leaf, node 1); node 1 = (leaf, leaf): no node changes, the walk starts at node 1
+    nodes = np.array([_node(BIG, _leaf(7), _union(A, B), 1), _node(A, _leaf(0), B, _leaf(1))])
+    out, first, start = _take_out(nodes)
+    assert first == 7 and start == 1 and out.tobytes() == nodes.tobytes()
+    # the same with the ground as child 1 and a leaf as its sibling: the walk starts at that leaf
+    nodes = np.array([_node(A, _leaf(3), BIG, _leaf(9))])
+    out, first, start = _take_out(nodes)
+    assert first == 9 and start == _leaf(3) and out.tobytes() == nodes.tobytes()
+
+
+def test_take_out_leaf_two_levels_down_shrinks_the_ancestors():
+    # root 0 = (node 1, node 2); node 1 = (node 3, leaf D); node 3 = (ground, node 4); node 4 = (A, B); node 2 = (C, C)
+    below3 = _union(BIG, _union(A, B))
+    below1 = _union(below3, D)
+    nodes = np.array([_node(below1, 1, C_, 2), _node(below3, 3, D, _leaf(5)), _node(C_, _leaf(6), C_, _leaf(6)),
+                      _node(BIG, _leaf(4), _union(A, B), 4), _node(A, _leaf(0), B, _leaf(1))])
+    out, first, start = _take_out(nodes)
+    assert first == 4 and start == 0
+    # node 1's slot for node 3 now holds node 4 with node 4's box; the root's slot for node 1 holds what is left below node 1
+    assert out[1]["ref0"] == 4 and _child_box(out[1], 0) == _union(A, B) and out[1]["ref1"] == _leaf(5) and _child_box(out[1], 1) == D
+    assert out[0]["ref0"] == 1 and _child_box(out[0], 0) == _union(_union(A, B), D) and _child_box(out[0], 1) == C_
+    assert out[2:].tobytes() == nodes[2:].tobytes()  # nothing else is touched (node 3 is no longer reachable)
+
+
+def test_take_out_finds_nothing_to_take():
+    small = np.array([_node(A, _leaf(0), B, _leaf(1))])
+    assert _take_out(small)[1:] == (NONE, 0)  # no leaf with half the tree's area
+    two = np.array([_node(BIG, _leaf(0, count=2), A, _leaf(2))])
+    assert _take_out(two)[1:] == (NONE, 0)  # a leaf of two spheres stays
+    # too deep: the ground hangs below the fourth level
+    deep = [_node(_union(BIG, A), k + 1, D, _leaf(20 + k)) for k in range(4)] + [_node(BIG, _leaf(9), A, _leaf(0))]
+    out, first, start = _take_out(np.array(deep))
+    assert (first, start) == (NONE, 0) and out.tobytes() == np.array(deep).tobytes()
+    assert _take_out(np.zeros(0, dtype=DEV_NODE), root=_leaf(0))[1:] == (NONE, _leaf(0))  # the tree is a single leaf
