@@ -143,10 +143,11 @@ __device__ __forceinline__ void sincos_2pi(double u, double& s, double& c) {
   c = ((k + 1) & 2) ? -c1 : c1;
 }
 
-// The same through a table of sin and cos at the 64th parts of a turn (in LDS, filled by stage_scene with the
-// function above): the remainder is at most 1/128 of a turn, where four terms of each series reach double
-// precision, and the angle-sum formulas put the two together.  About 2 ulp; half the instructions.
-constexpr uint32_t kTrigEntries = 64;
+// The same through a table of sin and cos at the 512th parts of a turn (8 KB of LDS, filled by stage_scene with the
+// function above): the remainder is at most 1/1024 of a turn (6.2e-3 rad), where two terms of the sine's series and three of
+// the cosine's reach double precision (the first terms left out are 6e-20 and 8e-17), and the angle-sum formulas put the two
+// together.  About 2 ulp; under half the instructions.
+constexpr uint32_t kTrigEntries = 512;
 struct TrigSeries {};  // no table: the polynomials over a quarter turn
 struct TrigTable {
   __attribute__((address_space(3))) double* tab;  // kTrigEntries x (sin, cos)
@@ -155,19 +156,16 @@ __device__ __forceinline__ void sincos_2pi(double u, double& s, double& c, TrigS
 __device__ __forceinline__ void sincos_2pi(double u, double& s, double& c, TrigTable t) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) d2 lds_d2;
-  const double q = rint((double)kTrigEntries * u);           // 0..64
-  const double f = fma(q, -1.0 / kTrigEntries, u);           // exact, |f| <= 1/128
+  const double q = rint((double)kTrigEntries * u);           // 0..kTrigEntries
+  const double f = fma(q, -1.0 / kTrigEntries, u);           // exact, |f| <= 1/(2*kTrigEntries)
   const uint32_t k = (uint32_t)(int)q & (kTrigEntries - 1u);
   const d2 sc = *(lds_d2*)(t.tab + 2u * k);
   const double a = f * local_const(6.28318530717958647692528676655900577);
   const double z = a * a;
-  double ps = local_const(-1.0 / 5040.0);
-  ps = fma(ps, z, local_const(1.0 / 120.0));
+  double ps = local_const(1.0 / 120.0);
   ps = fma(ps, z, local_const(-1.0 / 6.0));
   const double sa = fma(a * z, ps, a);
-  double pc = local_const(1.0 / 40320.0);
-  pc = fma(pc, z, local_const(-1.0 / 720.0));
-  pc = fma(pc, z, local_const(1.0 / 24.0));
+  double pc = local_const(1.0 / 24.0);
   pc = fma(pc, z, -0.5);
   const double ca = fma(pc, z, 1.0);
   s = fma(sc.x, ca, sc.y * sa);
