@@ -426,6 +426,7 @@ struct TreeView {
   uint32_t n_lds, n_sph_lds, n_aux_lds, n_mat_lds;
   uint32_t root;
   uint32_t first_leaf;  // see SceneDev
+  lds_double2* lfirst;  // LDS copy of that sphere's record
   float bound;
   float pad_bound;     // pad_for_bound(bound)
   TimeFrame time;      // the frame the node tests run in: the start of the queries' interval and the scene's time scale
@@ -780,10 +781,8 @@ __device__ __forceinline__ void trav_wide_step(Trav& tr, const TreeView& tv, con
 // direction has unit length, so the reference's a = |d|^2 is taken as 1.
 // Sphere::hit (src/sphere.rs:29-48) for the sphere in `slot`.  The direction has unit length, so
 // the reference's a = |d|^2 is taken as 1.
-template <bool kAllLds>
-__device__ __forceinline__ void sphere_test(Trav& tr, const TreeView& tv, uint32_t slot, double t_min) {
-  f64x2 s0, s1;
-  fetch_sphere<kAllLds>(tv, slot, s0, s1);
+// (s0, s1 = the sphere's record: centre x, y | centre z, radius)
+__device__ __forceinline__ void sphere_test_record(Trav& tr, const TreeView& tv, uint32_t slot, f64x2 s0, f64x2 s1, double t_min) {
   D3 oc = d3(tr.o.x - s0.x, tr.o.y - s0.y, tr.o.z - s1.x);
   double half_b = dot(oc, tr.d);
   double c = dot(oc, oc) - s1.y * s1.y;
@@ -801,13 +800,19 @@ __device__ __forceinline__ void sphere_test(Trav& tr, const TreeView& tv, uint32
     }
   }
 }
+template <bool kAllLds>
+__device__ __forceinline__ void sphere_test(Trav& tr, const TreeView& tv, uint32_t slot, double t_min) {
+  f64x2 s0, s1;
+  fetch_sphere<kAllLds>(tv, slot, s0, s1);
+  sphere_test_record(tr, tv, slot, s0, s1, t_min);
+}
 // The sphere that stands outside the tree (TreeView::first_leaf), tested when a query starts.  In the reference's tree
 // it is a leaf under the root whose box the query's origin lies in, so it is the first thing the walk would test anyway
 // (src/bvh.rs:50-84); here that costs no node step and no round of the leaf block.  Returns the number of tests made.
 template <bool kAllLds>
 __device__ __forceinline__ uint32_t trav_first(Trav& tr, const TreeView& tv, double t_min) {
   if (tv.first_leaf == kRefDone) return 0u;
-  sphere_test<kAllLds>(tr, tv, tv.first_leaf, t_min);
+  sphere_test_record(tr, tv, tv.first_leaf, tv.lfirst[0], tv.lfirst[1], t_min);  // its record has a copy in LDS whatever else is there
   return 1u;
 }
 // One leaf: each of its spheres in stored order.  Trees whose leaves all hold one sphere (what
@@ -957,7 +962,8 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
                                                 float time_scale = 0.0f) {
   lds_double* lcam = (lds_double*)smem;
   lds_double* ltrig = lcam + CAM_DOUBLES;
-  lds_float4* lnodes = (lds_float4*)(ltrig + 2 * kTrigEntries);
+  lds_double2* lfirst = (lds_double2*)(ltrig + 2 * kTrigEntries);
+  lds_float4* lnodes = (lds_float4*)(lfirst + 2);
   lds_double2* lsph = (lds_double2*)(lnodes + (kWide ? kWideLdsStride / 16 : kLdsNodeQuads) * sc.n_nodes_lds);
   lds_double2* laux = lsph + 2 * sc.n_spheres_lds;
   lds_double2* lmat = laux + sc.n_aux_lds;
@@ -971,6 +977,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
     const double* src = k < 3 ? cam->center : k < 6 ? cam->pixel00 : k < 9 ? cam->du : k < 12 ? cam->dv : k < 15 ? cam->disk_u : cam->disk_v;
     lcam[k] = src[k % 3];
   }
+  if (threadIdx.x < 2 && sc.first_leaf != kRefDone) lfirst[threadIdx.x] = gs[2 * sc.first_leaf + threadIdx.x];
   if (threadIdx.x < kTrigEntries) {
     double sn, cs;
     sincos_2pi((double)threadIdx.x * (1.0 / kTrigEntries), sn, cs);
@@ -1005,6 +1012,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
   // a tree that is in LDS as a whole is walked by LDS addresses (see stage_node)
   im.tv.root = (kAllLds && !kWide && !(sc.root & kRefLeaf)) ? lds_node_address(lnodes, sc.root) : sc.root;
   im.tv.first_leaf = sc.first_leaf;
+  im.tv.lfirst = lfirst;
   im.tv.bound = sc.bound;
   im.tv.pad_bound = uniform_f32(pad_for_bound(sc.bound));
   im.tv.time = uniform_frame(time_frame(t_min, time_scale > 0.0f ? time_scale : time_scale_for(sc.bound)));

@@ -577,7 +577,7 @@ hipError_t static_scratch(int device, void** ptr, size_t* bytes) {
 // --------------------------------------------------------------- launchers ----
 size_t lds_node_bytes() { return kLdsNodeQuads * 16; }
 size_t lds_wide_node_bytes() { return kWideLdsStride; }
-size_t lds_fixed_bytes() { return CAM_DOUBLES * 8 + kTrigEntries * 16; }  // camera constants, sin/cos table
+size_t lds_fixed_bytes() { return CAM_DOUBLES * 8 + kTrigEntries * 16 + 32; }  // camera constants, sin/cos table, the record of the sphere outside the tree
 size_t tree_lds_bytes(const SceneDev& sc) {
   if (sc.wide)
     return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * kWideLdsStride + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
