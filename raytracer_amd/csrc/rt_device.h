@@ -718,31 +718,43 @@ __device__ __forceinline__ void trav_push(Trav& tr, const HybridStack& st, uint3
   tr.tos = ref;
 }
 // One four-wide node: test the four child boxes, continue with the one entered first, set the others aside.
-__device__ __forceinline__ void trav_wide_step(Trav& tr, const TreeView& tv, const HybridStack& st) {
-  // tr.offx/y/z: 16 where the ray travels down the axis (its near planes are the high ones), else 0
-  f32x4 NX, FX, NY, FY, NZ, FZ;
+struct WideData {
+  f32x4 NX, FX, NY, FY, NZ, FZ;  // per axis the four children's planes met first and those met last
   u32x4 refs;
-  if (tr.cur < tv.n_lds) {
+};
+__device__ __forceinline__ WideData wide_fetch(const Trav& tr, const TreeView& tv, uint32_t node) {
+  // tr.offx/y/z: 16 where the ray travels down the axis (its near planes are the high ones), else 0
+  WideData w;
+  if (node < tv.n_lds) {
     typedef __attribute__((address_space(3))) char lds_char;
-    lds_char* p = (lds_char*)tv.lnodes + __umul24(tr.cur, kWideLdsStride);
-    NX = *(lds_float4*)(p + tr.offx);
-    FX = *(lds_float4*)(p + (tr.offx ^ 16u));
-    NY = *(lds_float4*)(p + 32u + tr.offy);
-    FY = *(lds_float4*)(p + 32u + (tr.offy ^ 16u));
-    NZ = *(lds_float4*)(p + 64u + tr.offz);
-    FZ = *(lds_float4*)(p + 64u + (tr.offz ^ 16u));
-    refs = *(lds_u32x4*)(p + 96);
+    lds_char* p = (lds_char*)tv.lnodes + __umul24(node, kWideLdsStride);
+    w.NX = *(lds_float4*)(p + tr.offx);
+    w.FX = *(lds_float4*)(p + (tr.offx ^ 16u));
+    w.NY = *(lds_float4*)(p + 32u + tr.offy);
+    w.FY = *(lds_float4*)(p + 32u + (tr.offy ^ 16u));
+    w.NZ = *(lds_float4*)(p + 64u + tr.offz);
+    w.FZ = *(lds_float4*)(p + 64u + (tr.offz ^ 16u));
+    w.refs = *(lds_u32x4*)(p + 96);
   } else {
     const char* base = reinterpret_cast<const char*>(tv.gnodes);
-    const uint32_t at = tr.cur * 128u;
-    NX = *reinterpret_cast<const f32x4*>(base + (size_t)(at + tr.offx));
-    FX = *reinterpret_cast<const f32x4*>(base + (size_t)(at + (tr.offx ^ 16u)));
-    NY = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 32u + tr.offy));
-    FY = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 32u + (tr.offy ^ 16u)));
-    NZ = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 64u + tr.offz));
-    FZ = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 64u + (tr.offz ^ 16u)));
-    refs = *reinterpret_cast<const u32x4*>(base + (size_t)(at + 96u));
+    const uint32_t at = node * 128u;
+    w.NX = *reinterpret_cast<const f32x4*>(base + (size_t)(at + tr.offx));
+    w.FX = *reinterpret_cast<const f32x4*>(base + (size_t)(at + (tr.offx ^ 16u)));
+    w.NY = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 32u + tr.offy));
+    w.FY = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 32u + (tr.offy ^ 16u)));
+    w.NZ = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 64u + tr.offz));
+    w.FZ = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 64u + (tr.offz ^ 16u)));
+    w.refs = *reinterpret_cast<const u32x4*>(base + (size_t)(at + 96u));
   }
+  return w;
+}
+struct WideChoice {
+  bool h0, h1, h2, h3, is0;
+  uint32_t first, next;
+};
+__device__ __forceinline__ WideChoice wide_choose(const Trav& tr, const WideData& w) {
+  const f32x4 &NX = w.NX, &FX = w.FX, &NY = w.NY, &FY = w.FY, &NZ = w.NZ, &FZ = w.FZ;
+  const u32x4& refs = w.refs;
   const RayBox& q = tr.q;
   const float tn0 = max3_raw(fmaf(NX.x, q.rx, q.nx.x), fmaf(NY.x, q.ry, q.ny.x), fma_clamp(NZ.x, q.rz, q.nz.x));
   const float tn1 = max3_raw(fmaf(NX.y, q.rx, q.nx.x), fmaf(NY.y, q.ry, q.ny.x), fma_clamp(NZ.y, q.rz, q.nz.x));
@@ -752,29 +764,39 @@ __device__ __forceinline__ void trav_wide_step(Trav& tr, const TreeView& tv, con
   const float tf1 = min3_raw(fmaf(FX.y, q.rx, q.nx.y), fmaf(FY.y, q.ry, q.ny.y), min_raw(fmaf(FZ.y, q.rz, q.nz.y), tr.tmaxf));
   const float tf2 = min3_raw(fmaf(FX.z, q.rx, q.nx.y), fmaf(FY.z, q.ry, q.ny.y), min_raw(fmaf(FZ.z, q.rz, q.nz.y), tr.tmaxf));
   const float tf3 = min3_raw(fmaf(FX.w, q.rx, q.nx.y), fmaf(FY.w, q.ry, q.ny.y), min_raw(fmaf(FZ.w, q.rz, q.nz.y), tr.tmaxf));
-  bool h0 = tn0 <= tf0, h1 = tn1 <= tf1, h2 = tn2 <= tf2, h3 = tn3 <= tf3;
+  WideChoice c;
+  c.h0 = tn0 <= tf0, c.h1 = tn1 <= tf1, c.h2 = tn2 <= tf2, c.h3 = tn3 <= tf3;
   // (a node has at least two children; an absent child's box is inverted and infinite, so it is never hit:
   // inf * r + c is +inf on its near side and -inf on its far side, or NaN on both, which the min/max drop, on an
   // axis the ray does not move along -- never on all three)
   const float inf = __builtin_inff();
-  const float t0 = h0 ? tn0 : inf, t1 = h1 ? tn1 : inf, t2 = h2 ? tn2 : inf, t3 = h3 ? tn3 : inf;
+  const float t0 = c.h0 ? tn0 : inf, t1 = c.h1 ? tn1 : inf, t2 = c.h2 ? tn2 : inf, t3 = c.h3 ? tn3 : inf;
   const float m = min3_raw(t0, t1, min_raw(t2, t3));
   // the child entered first (the lowest of equals); selects, not branches
-  const bool is0 = t0 == m, is1 = t1 == m, is2 = t2 == m;
-  const uint32_t first = is0 ? 0u : is1 ? 1u : is2 ? 2u : 3u;
-  const uint32_t next = is0 ? refs.x : is1 ? refs.y : is2 ? refs.z : refs.w;
+  c.is0 = t0 == m;
+  const bool is1 = t1 == m, is2 = t2 == m;
+  c.first = c.is0 ? 0u : is1 ? 1u : is2 ? 2u : 3u;
+  c.next = c.is0 ? refs.x : is1 ? refs.y : is2 ? refs.z : refs.w;
+  return c;
+}
+__device__ __forceinline__ void wide_apply(Trav& tr, const HybridStack& st, const u32x4& refs, const WideChoice& c) {
   // The others that are hit wait on the stack, pushed in the order 3, 2, 1, 0 (last pushed, first visited: the
   // later children of a node come from the larger subtree that was opened up).  (Measured: storing to three slots
   // unconditionally instead of these branches, and one generic load sequence for LDS and global nodes, were both slower.)
-  if (h3 && first != 3u) trav_push(tr, st, refs.w);
-  if (h2 && first != 2u) trav_push(tr, st, refs.z);
-  if (h1 && first != 1u) trav_push(tr, st, refs.y);
-  if (h0 && !is0) trav_push(tr, st, refs.x);
-  if (h0 || h1 || h2 || h3) {
-    tr.cur = next;
+  if (c.h3 && c.first != 3u) trav_push(tr, st, refs.w);
+  if (c.h2 && c.first != 2u) trav_push(tr, st, refs.z);
+  if (c.h1 && c.first != 1u) trav_push(tr, st, refs.y);
+  if (c.h0 && !c.is0) trav_push(tr, st, refs.x);
+  if (c.h0 || c.h1 || c.h2 || c.h3) {
+    tr.cur = c.next;
   } else {
     trav_pop(tr, st, 0u);
   }
+}
+__device__ __forceinline__ void trav_wide_step(Trav& tr, const TreeView& tv, const HybridStack& st) {
+  const WideData w = wide_fetch(tr, tv, tr.cur);
+  const WideChoice c = wide_choose(tr, w);
+  wide_apply(tr, st, w.refs, c);
 }
 
 // One leaf: Sphere::hit (src/sphere.rs:29-48) for each of its spheres.  The
