@@ -95,11 +95,11 @@ struct DeviceGuard {  // makes a device current for the duration of a call
 
 // Tunables (rt_debug_set).  Atomics: a render call reads each of them once, when it starts.
 // Lanes (of 64) that must want the inner-node block for a wave to run it without looking at the other blocks.
-std::atomic<uint32_t> g_inner_min{10};
+std::atomic<uint32_t> g_inner_min{0};  // 0 (only as the initial value): 10 for the two-wide walk, 6 for the four-wide one
 // Lanes that must want the other traversal block (inner or leaf) for it to run in the same round as the one that is due.
 std::atomic<uint32_t> g_both_min{8};
 // Lanes waiting at leaves that make the leaf block run between inner-node rounds.
-std::atomic<uint32_t> g_leaf_min{0};  // 0 (only as the initial value): 8 for the two-wide walk, 10 for the four-wide one
+std::atomic<uint32_t> g_leaf_min{8};
 // Samples of one pixel that make a unit of work (the sample range is cut into chunks of about this size).
 std::atomic<uint32_t> g_chunk_spp{64};
 std::atomic<uint32_t> g_first_leaf{1};  // 0: keep a leaf under the root inside the walk (for measurements)
@@ -810,9 +810,9 @@ int plan_render(const Replica& rp, const CameraDev& cam, uint64_t seed, const rt
     P.time_scale = std::ldexp(1.0f, -(e + 5));
   }
   P.inner_min = g_inner_min.load();
+  if (P.inner_min == 0) P.inner_min = P.sc.wide ? 6u : 10u;  // the four-wide walk waits on its loads: it gains from running with fewer lanes
   P.both_min = g_both_min.load();
   P.leaf_min = g_leaf_min.load();
-  if (P.leaf_min == 0) P.leaf_min = P.sc.wide ? 10u : 8u;  // three node steps per round bring lanes to leaves faster than one
   if (P.sc.wide) {  // the stack entries beyond those kept in LDS
     if (P.sc.stack_cap > P.sc.lds_stack) {
       P.sc.gstack_stride = (uint32_t)rp.num_cus * kWorkgroup;

@@ -8,7 +8,7 @@ for round in 1 2; do
     for cfg in "c5 3840 64" "c3 3840 32" "c4 7680 8"; do
       set -- $cfg
       echo "== $v $1"
-      timeout -k 10 200 python3 tools/perf_sweep.py inner_min 10 --config $1 --width $2 --spp $3 --rounds 2 || exit 1
+      timeout -k 10 200 python3 tools/perf_sweep.py both_min 8 --config $1 --width $2 --spp $3 --rounds 2 || exit 1
     done
   done
 done
