@@ -695,12 +695,27 @@ struct ChunkPlan {
 };
 ChunkPlan plan_chunks(uint32_t spp, uint64_t pixels, uint64_t limit) {
   const uint64_t target = g_target_units.load();
+  const uint64_t fit = std::max<uint64_t>(1, limit / (pixels * 24));  // chunks whose partial sums fit in the workspace
   uint64_t want = std::max<uint64_t>(std::min<uint64_t>(16, spp / std::max<uint32_t>(1, g_chunk_spp.load())), (target + pixels - 1) / pixels);
-  want = std::min<uint64_t>(want, std::max<uint64_t>(1, limit / (pixels * 24)));
-  uint32_t n_chunks = (uint32_t)std::min<uint64_t>(spp, std::max<uint64_t>(1, want));
-  const uint32_t chunk_spp = (spp + n_chunks - 1) / n_chunks;
-  n_chunks = (spp + chunk_spp - 1) / chunk_spp;
-  return ChunkPlan{n_chunks, chunk_spp};
+  // With a multiple of four chunks the 64 lanes of a wave start on a quarter of a tile in four chunks (quad_tiles), which
+  // keeps their rays closer together: worth 4-9 % on scenes that are walked out of L1/L2.  Eight chunks where the
+  // samples allow (at least four samples each), else four.
+  if (g_quad_tiles.load() && spp >= 16) want = std::max<uint64_t>(want, spp >= 32 ? 8 : 4);
+  want = std::min<uint64_t>(std::min<uint64_t>(want, fit), spp);
+  auto cut = [&](uint32_t chunk_spp) { return ChunkPlan{(spp + chunk_spp - 1) / chunk_spp, chunk_spp}; };
+  ChunkPlan plan = cut((uint32_t)((spp + want - 1) / std::max<uint64_t>(1, want)));
+  if (g_quad_tiles.load() && want >= 4 && plan.n_chunks % 4 != 0) {  // a chunk size next to it that gives a multiple of four
+    for (int d : {1, -1, 2, -2, 3, -3}) {
+      const long c = (long)plan.chunk_spp + d;
+      if (c < 1) continue;
+      const ChunkPlan other = cut((uint32_t)c);
+      if (other.n_chunks % 4 == 0 && other.n_chunks <= fit && other.n_chunks >= 4) {
+        plan = other;
+        break;
+      }
+    }
+  }
+  return plan;
 }
 
 uint32_t shard_tile_rows(const rt_shard& sh) {  // tile rows (8 pixel rows) of the rectangle that belong to the shard
