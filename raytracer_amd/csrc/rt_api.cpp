@@ -106,7 +106,7 @@ std::atomic<uint32_t> g_first_leaf{1};  // 0: keep a leaf under the root inside 
 std::atomic<uint32_t> g_quad_tiles{1};
 // Fewest units of work a call is cut into (32 per lane of the chip).
 std::atomic<uint64_t> g_target_units{1u << 25};
-std::atomic<uint64_t> g_batches_per_wave{32};
+std::atomic<uint64_t> g_batches_per_wave{64};
 // Test hook: scenes created while this is set keep their traversal stacks in global memory, as very deep trees must.
 std::atomic<bool> g_force_global_stack{false};
 // Test hook: rt_render_multi brings the frames of a sample split together through a copy on the first device even

@@ -634,7 +634,7 @@ def test_frame_does_not_depend_on_scheduling(world):
     L = rt._lib.lib()
     cam = rt.config_rtiow(image_width=120, samples_per_pixel=24, max_depth=50).camera()
     want, st = cam.render_sum(world, seed=77)
-    defaults = {b"inner_min": 10, b"leaf_min": 8, b"both_min": 8, b"batches_per_wave": 32, b"quad_tiles": 1}
+    defaults = {b"inner_min": 10, b"leaf_min": 8, b"both_min": 8, b"batches_per_wave": 64, b"quad_tiles": 1}
     try:
         for knobs in [{b"inner_min": 1, b"leaf_min": 1, b"both_min": 1}, {b"inner_min": 64, b"leaf_min": 64, b"both_min": 64},
                       {b"inner_min": 20, b"leaf_min": 3}, {b"batches_per_wave": 1}, {b"batches_per_wave": 1000, b"both_min": 33},

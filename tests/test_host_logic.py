@@ -197,7 +197,7 @@ def test_debug_knobs_refuse_values_that_would_hang_a_wave():
     for bad in (-1.0, 65.0, float("nan")):
         assert L.rt_debug_set(b"both_min", C.c_double(bad)) == 1
     assert L.rt_debug_set(b"both_min", C.c_double(0.0)) == 0 and L.rt_debug_set(b"both_min", C.c_double(8.0)) == 0
-    assert L.rt_debug_set(b"batches_per_wave", C.c_double(0.0)) == 1 and L.rt_debug_set(b"batches_per_wave", C.c_double(32.0)) == 0
+    assert L.rt_debug_set(b"batches_per_wave", C.c_double(0.0)) == 1 and L.rt_debug_set(b"batches_per_wave", C.c_double(64.0)) == 0
     assert L.rt_debug_set(b"no_such_knob", C.c_double(1.0)) == 1
 
 
