@@ -104,6 +104,8 @@ std::atomic<uint32_t> g_leaf_min{8};
 std::atomic<uint32_t> g_chunk_spp{64};
 std::atomic<uint32_t> g_first_leaf{1};  // 0: keep a leaf under the root inside the walk (for measurements)
 std::atomic<uint32_t> g_quad_tiles{1};
+// Longest entry list a tile's camera rays start from (rt_launch.h); 0: every ray starts at the root.
+std::atomic<uint32_t> g_tile_cuts{kCutEntries};
 // Fewest units of work a call is cut into (32 per lane of the chip).
 std::atomic<uint64_t> g_target_units{1u << 25};
 std::atomic<uint64_t> g_batches_per_wave{64};
@@ -129,6 +131,8 @@ struct Workspace {
   size_t partial_cap = 0;
   uint32_t* gstack = nullptr;  // traversal stacks of trees too deep for LDS
   size_t gstack_cap = 0;
+  uint32_t* cuts = nullptr;  // the tiles' entry lists
+  size_t cuts_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool fixed = false;  // carved out of the library's static device array: cannot grow, owns nothing
   ~Workspace() {
@@ -136,6 +140,7 @@ struct Workspace {
     if (counters) (void)hipFree(counters);
     if (partial) (void)hipFree(partial);
     if (gstack) (void)hipFree(gstack);
+    if (cuts) (void)hipFree(cuts);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
   }
@@ -358,23 +363,31 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   const uint32_t depth = tree_depth ? tree_depth : 1;
   const size_t reserve = lds_fixed_bytes() + 64;
   const bool stack_in_lds = depth <= max_depth && !g_force_global_stack.load();
-  const size_t stack_bytes = stack_in_lds ? (size_t)(depth + kStackSpareRows) * kWorkgroup * 4 : 0;
-  size_t room = kLdsPerCu - stack_bytes - reserve;
   const size_t node_bytes = n_dev_nodes * sizeof(DevNode), sph_bytes = n * sizeof(DevSphere);
   const size_t aux_bytes = n * sizeof(DevSphereAux), mat_bytes = nm * 32, used_mat_bytes = n_used * 32;  // nm: records in the table
-  uint32_t n_nodes_lds = (uint32_t)std::min(n_dev_nodes, room / lds_node_bytes());
-  room -= n_nodes_lds * lds_node_bytes();
-  uint32_t n_sph_lds = 0, n_aux_lds = 0, n_mat_lds = 0;
-  if (n_nodes_lds == n_dev_nodes) {
-    if (sph_bytes <= room) {
-      n_sph_lds = (uint32_t)n;
-      room -= sph_bytes;
-      if (aux_bytes <= room) {
-        n_aux_lds = (uint32_t)n;
-        room -= aux_bytes;
-        if (used_mat_bytes <= room) n_mat_lds = (uint32_t)n_used;
+  // Camera rays that start from an entry list of k nodes (rt_launch.h) need k - 2 stack entries more than the tree is
+  // deep: lists of four if the scene still fits in LDS with two more rows of stacks, else of three or two.
+  uint32_t n_nodes_lds = 0, n_sph_lds = 0, n_aux_lds = 0, n_mat_lds = 0, cut_rows = 0;
+  for (uint32_t extra : {2u, 1u, 0u}) {
+    const size_t stack_bytes = stack_in_lds ? (size_t)(depth + kStackSpareRows + extra) * kWorkgroup * 4 : 0;
+    cut_rows = extra;
+    n_nodes_lds = n_sph_lds = n_aux_lds = n_mat_lds = 0;
+    if (stack_bytes + reserve > kLdsPerCu) continue;
+    size_t room = kLdsPerCu - stack_bytes - reserve;
+    n_nodes_lds = (uint32_t)std::min(n_dev_nodes, room / lds_node_bytes());
+    room -= n_nodes_lds * lds_node_bytes();
+    if (n_nodes_lds == n_dev_nodes) {
+      if (sph_bytes <= room) {
+        n_sph_lds = (uint32_t)n;
+        room -= sph_bytes;
+        if (aux_bytes <= room) {
+          n_aux_lds = (uint32_t)n;
+          room -= aux_bytes;
+          if (used_mat_bytes <= room) n_mat_lds = (uint32_t)n_used;
+        }
       }
     }
+    if (!stack_in_lds || (n_nodes_lds == n_dev_nodes && n_sph_lds == n && n_aux_lds == n && n_mat_lds == n_used)) break;
   }
 
   // A sphere as large as the scene (the reference scene's ground) is a one-sphere leaf near the top of the host's tree:
@@ -421,12 +434,12 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
       rp.d_nodes = d_wide;  // owned by the replica from here on, also if the call failed half-way
       RT_HIP(e);
       n_final_nodes = n_wide;
-      wide_stack_entries = 3 * levels + 1;  // at most three children set aside per level
+      wide_stack_entries = 3 * levels + 1 + (kCutEntries - 2);  // at most three children set aside per level; a camera ray's entry list
       wide_bound = tree.bound;
     } else {
       if (wide_cache->nodes.empty()) *wide_cache = collapse_wide(wide_peel ? host_nodes : flat.nodes.data(), n_dev_nodes, wide_peel ? walk_root : flat.root);
       n_final_nodes = wide_cache->nodes.size();
-      wide_stack_entries = wide_cache->stack_entries;
+      wide_stack_entries = wide_cache->stack_entries + (kCutEntries - 2);
       wide_bound = std::fmax(wide_cache->bound, flat.bound);
     }
     lds_stack = g_force_global_stack.load() ? 0u : std::min<uint32_t>(wide_stack_entries, g_wide_lds_stack.load());
@@ -473,7 +486,8 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   dev.n_spheres_lds = n_sph_lds;
   dev.n_aux_lds = n_aux_lds;
   dev.n_materials_lds = n_mat_lds;
-  dev.stack_cap = wide ? wide_stack_entries : depth;
+  dev.stack_cap = wide ? wide_stack_entries : depth + cut_rows;
+  dev.cut_k = wide ? kCutEntries : cut_rows + 2;
   dev.stack_in_lds = wide ? 1u : (stack_in_lds ? 1u : 0u);
   dev.wide = wide ? 1u : 0u;
   dev.lds_stack = lds_stack;
@@ -733,7 +747,7 @@ int check_shard(const CameraDev& cam, const rt_shard& sh, const char* who) {
 }
 
 // Takes a workspace from the replica's pool (or makes one) and grows it to the call's needs.
-int acquire_workspace(Replica& rp, size_t partial_bytes, size_t gstack_bytes, std::unique_ptr<Workspace>* out) {
+int acquire_workspace(Replica& rp, size_t partial_bytes, size_t gstack_bytes, size_t cuts_bytes, std::unique_ptr<Workspace>* out) {
   std::unique_ptr<Workspace> ws;
   {
     std::lock_guard<std::mutex> lock(rp.pool_mu);
@@ -750,6 +764,7 @@ int acquire_workspace(Replica& rp, size_t partial_bytes, size_t gstack_bytes, st
   }
   RT_HIP(grow_device((void**)&ws->partial, &ws->partial_cap, partial_bytes));
   RT_HIP(grow_device((void**)&ws->gstack, &ws->gstack_cap, gstack_bytes));
+  RT_HIP(grow_device((void**)&ws->cuts, &ws->cuts_cap, cuts_bytes));
   *out = std::move(ws);
   return RT_OK;
 }
@@ -761,7 +776,9 @@ void release_workspace(Replica& rp, std::unique_ptr<Workspace> ws) {
 struct Launch {  // what enqueue_render worked out, for the caller to size the workspace and to fill the stats
   RenderParams P;
   int blocks = 0;
-  size_t partial_bytes = 0, gstack_bytes = 0;
+  size_t partial_bytes = 0, gstack_bytes = 0, cuts_bytes = 0;
+  uint32_t cut_k = 0;                 // entries per tile's entry list (0: none are made)
+  double beam_rho0 = 0.0, beam_h = 0.0;  // see launch_tile_cuts
   uint64_t samples = 0;
   bool nothing = false;  // no pixel, no sample or max_depth 0: no launch
 };
@@ -838,6 +855,15 @@ int plan_render(const Replica& rp, const CameraDev& cam, uint64_t seed, const rt
     L->gstack_bytes = (size_t)P.sc.gstack_stride * P.sc.stack_cap * 4;
   }
   L->partial_bytes = P.direct ? 0 : (size_t)plan.n_chunks * tw * P.local_rows * 24;
+  L->cut_k = std::min(g_tile_cuts.load(), rp.dev.cut_k);
+  if (L->cut_k >= 1) {
+    // |dx U + dy V| for (dx, dy) in the unit disk, and |a du + b dv| for |a|, |b| <= 4 (the tile's middle to its edge)
+    auto dot3 = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    const double uu = dot3(cam.disk_u, cam.disk_u), vv = dot3(cam.disk_v, cam.disk_v), uv = std::fabs(dot3(cam.disk_u, cam.disk_v));
+    L->beam_rho0 = cam.defocus ? std::sqrt(std::max(uu, vv) + uv) * (1.0 + 1e-9) : 0.0;
+    L->beam_h = 4.0 * std::sqrt(dot3(cam.du, cam.du) + dot3(cam.dv, cam.dv) + 2.0 * std::fabs(dot3(cam.du, cam.dv))) * (1.0 + 1e-9);
+    L->cuts_bytes = (size_t)P.n_tiles * kCutEntries * 4;
+  }
   // One persistent workgroup per CU (fewer if there is less work than that).
   L->blocks = rp.num_cus;
   const uint64_t wgs_needed = (n_items + (kWorkgroup / 64) - 1) / (kWorkgroup / 64);
@@ -854,8 +880,14 @@ int enqueue_render(Launch& L, Workspace& ws, double* out_dev, hipStream_t stream
   P.sc.gstack = ws.gstack;
   P.out = P.direct ? out_dev : ws.partial;
   if (ws.ev0) RT_HIP(hipEventRecord(ws.ev0, stream));
-  RT_HIP(launch_render(P, L.blocks, profile, stream));
   *launches = 1;
+  P.cuts = nullptr;
+  if (L.cut_k >= 1 && ws.cuts) {
+    RT_HIP(launch_tile_cuts(P.sc, P.cam, L.beam_rho0, L.beam_h, P.x0, P.y0, P.tiles_x, P.n_tiles, P.row_first, P.row_stride, L.cut_k, ws.cuts, stream));
+    P.cuts = ws.cuts;
+    ++*launches;
+  }
+  RT_HIP(launch_render(P, L.blocks, profile, stream));
   if (!P.direct) {
     RT_HIP(launch_reduce_chunks(ws.partial, out_dev, P.n_chunks, P.x0, P.y0, P.y1, P.x1 - P.x0, P.local_rows, P.row_first, P.row_stride, P.cam.width,
                                 stream));
@@ -907,7 +939,7 @@ int render_shard(Replica& rp, const CameraDev& cam, uint64_t seed, const rt_shar
     return RT_OK;
   }
   std::unique_ptr<Workspace> ws;
-  rc = acquire_workspace(rp, L.partial_bytes, L.gstack_bytes, &ws);
+  rc = acquire_workspace(rp, L.partial_bytes, L.gstack_bytes, L.cuts_bytes, &ws);
   if (rc) return rc;
   const bool profile = std::getenv("RT_PROFILE_BLOCKS") != nullptr;
   uint32_t launches = 0;
@@ -1346,13 +1378,25 @@ int rt_render_device_noalloc(const rt_scene* sc, const rt_config* cfg, uint64_t 
       if (stats && cam.max_depth == 0) stats->samples = L.samples;
       return RT_OK;
     }
-    if (L.gstack_bytes)
-      return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: this scene's tree is too deep for traversal stacks in LDS and needs " +
-                                    std::to_string(L.gstack_bytes) + " bytes of stacks in global memory; use rt_render_device");
     if (L.partial_bytes > ws.partial_cap)
       return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: the request needs " + std::to_string(L.partial_bytes) +
                                     " bytes of per-chunk sums, the static workspace holds " + std::to_string(ws.partial_cap) +
                                     "; render a smaller tile or sample range per call, or use rt_render_device");
+    // Behind the per-chunk sums: the traversal stacks' overflow columns (scenes walked through the four-wide tree, very deep
+    // trees), which must fit, and the tiles' entry lists, which are left out if they do not (the frame is the same without).
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    char* const base = reinterpret_cast<char*>(ws.counters);
+    const size_t total = ws.partial_cap + 256;
+    size_t used = 256 + up(L.partial_bytes);
+    if (L.gstack_bytes) {
+      if (used + L.gstack_bytes > total)
+        return fail(RT_ERR_LIMIT, "rt_render_device_noalloc: the request needs " + std::to_string(L.partial_bytes) + " bytes of per-chunk sums and " +
+                                      std::to_string(L.gstack_bytes) + " bytes of traversal stacks, the static workspace holds " +
+                                      std::to_string(total - 256) + "; render a smaller tile or sample range per call, or use rt_render_device");
+      ws.gstack = reinterpret_cast<uint32_t*>(base + used);
+      used += up(L.gstack_bytes);
+    }
+    if (L.cuts_bytes && used + L.cuts_bytes <= total) ws.cuts = reinterpret_cast<uint32_t*>(base + used);
     uint32_t launches = 0;
     rc = enqueue_render(L, ws, rgb_sum_dev, static_cast<hipStream_t>(stream), false, &launches);
     if (rc) return rc;
@@ -1581,6 +1625,12 @@ int rt_debug_set(const char* name, double value) {
     }
     if (key == "first_leaf") {  // takes effect for scenes created afterwards
       g_first_leaf.store(value != 0.0 ? 1u : 0u);
+      return RT_OK;
+    }
+    if (key == "tile_cuts") {
+      if (!(value >= 0.0 && value <= (double)kCutEntries) || value != std::floor(value))
+        return fail(RT_ERR_INVALID, "rt_debug_set: tile_cuts must be a whole number in 0 .. " + std::to_string(kCutEntries));
+      g_tile_cuts.store((uint32_t)value);
       return RT_OK;
     }
     if (key == "quad_tiles") {

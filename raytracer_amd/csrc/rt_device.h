@@ -970,13 +970,15 @@ __device__ __forceinline__ bool scatter(const TreeView& tv, uint32_t mat, D3 d, 
 
 // ------------------------------------------------------------ LDS image ----
 // LDS image of a workgroup:
-//   [camera constants][sin/cos table][top-of-tree nodes][sphere slots][slot shading data][materials][per-lane stacks]
+//   [camera constants][sin/cos table][sphere outside the tree][entry lists][top-of-tree nodes][sphere slots][slot shading data][materials][per-lane stacks]
 struct LdsImage {
   TreeView tv;
   CamLds cam;
   TrigTable trig;
+  lds_u32* ring;  // per wave kCutRing entry lists of kCutEntries words (see rt_launch.h)
   lds_u32* stack_base;
 };
+constexpr uint32_t kRingWords = (kWorkgroup / 64u) * kCutRing * kCutEntries;
 
 // `t_min`: where the intervals of the kernel's queries start; `time_scale`: see TimeFrame (0: from the scene's extent).
 template <bool kAllLds, bool kWide = false>
@@ -985,7 +987,8 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
   lds_double* lcam = (lds_double*)smem;
   lds_double* ltrig = lcam + CAM_DOUBLES;
   lds_double2* lfirst = (lds_double2*)(ltrig + 2 * kTrigEntries);
-  lds_float4* lnodes = (lds_float4*)(lfirst + 2);
+  lds_u32* ring = (lds_u32*)(lfirst + 2);
+  lds_float4* lnodes = (lds_float4*)(ring + kRingWords);
   lds_double2* lsph = (lds_double2*)(lnodes + (kWide ? kWideLdsStride / 16 : kLdsNodeQuads) * sc.n_nodes_lds);
   lds_double2* laux = lsph + 2 * sc.n_spheres_lds;
   lds_double2* lmat = laux + sc.n_aux_lds;
@@ -1000,12 +1003,13 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
     lcam[k] = src[k % 3];
   }
   if (threadIdx.x < 2 && sc.first_leaf != kRefDone) lfirst[threadIdx.x] = gs[2 * sc.first_leaf + threadIdx.x];
-  if (threadIdx.x < kTrigEntries) {
+  for (uint32_t i = threadIdx.x; i < kTrigEntries; i += wg) {
     double sn, cs;
-    sincos_2pi((double)threadIdx.x * (1.0 / kTrigEntries), sn, cs);
-    ltrig[2 * threadIdx.x] = sn;
-    ltrig[2 * threadIdx.x + 1] = cs;
+    sincos_2pi((double)i * (1.0 / kTrigEntries), sn, cs);
+    ltrig[2 * i] = sn;
+    ltrig[2 * i + 1] = cs;
   }
+  for (uint32_t i = threadIdx.x; i < kRingWords; i += wg) ring[i] = kRefDone;
   if (kWide) {  // four-wide nodes are staged as they are, 80 bytes apart
     for (uint32_t i = threadIdx.x; i < kWideStagedQuads * sc.n_nodes_lds; i += wg) {
       const uint32_t node = i / kWideStagedQuads, quad = i - node * kWideStagedQuads;
@@ -1041,6 +1045,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
   im.tv.single_leaves = sc.single_leaves != 0u;
   im.cam.p = lcam;
   im.trig.tab = ltrig;
+  im.ring = ring;
   im.stack_base = stack_base;
   return im;
 }

@@ -191,6 +191,13 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
   };
   const uint32_t lane = threadIdx.x & 63u;
   constexpr uint32_t kNoUnit = 0xffffffffu;
+  // Camera rays start from their tile's entry list (rt_launch.h).  A wave keeps the lists of its last kCutRing batches in
+  // LDS; a lane remembers which of them its unit belongs to in the top two bits of `unit`, kCutRing meaning none: a lane
+  // still at work on a unit when the wave's ring comes round to that unit's place loses its list and starts its
+  // remaining camera rays at the root.
+  constexpr uint32_t kUnitChunk = 0x3fffffffu, kSlotShift = 30u;
+  lds_u32* const my_ring = im.ring + (threadIdx.x >> 6) * (kCutRing * kCutEntries);
+  uint32_t wave_slot = kCutRing, wave_serial = 0;  // the ring place of the wave's current batch; batches taken so far
 
   // A unit of work is one pixel's samples of one chunk of the sample range.  A wave takes a batch
   // (some or all chunks of one 8x8 tile) at a time from the global counter and its lanes share out
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
   // instead of idling, and all lanes of a wave look at the same part of the scene.  The samples
   // of a unit are summed by one lane in index order and the chunks of a pixel are added in chunk
   // order afterwards, so the sums do not depend on which lane gets which unit or when.
-  uint32_t unit = kNoUnit;      // the chunk index of the lane's unit, or kNoUnit
+  uint32_t unit = kNoUnit;      // the chunk index of the lane's unit (and in its top two bits where the unit's entry list is, see cut_slot), or kNoUnit
   uint32_t pij = 0;             // the unit's pixel: i | j << 16
   uint32_t s = 0, s_last = 0;   // next sample and end of the unit's sample range (s == s_last: unit finished)
 #define RTA_I (pij & 0xffffu)
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
       // the partial sums hold the call's own tile rows only, packed: row (tile row / row_stride) * 8 + row within the tile
       const uint32_t tile_w = P.x1 - P.x0, rel = j - P.y0;
       const uint32_t row = P.row_stride == 1u ? rel : ((rel >> 3) / P.row_stride) * 8u + (rel & 7u);
-      double* px = P.out + 3 * ((size_t)unit * tile_w * P.local_rows + (size_t)row * tile_w + (i - P.x0));
+      double* px = P.out + 3 * ((size_t)(unit & kUnitChunk) * tile_w * P.local_rows + (size_t)row * tile_w + (i - P.x0));
       px[0] = acc.x;
       px[1] = acc.y;
       px[2] = acc.z;
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           tr.cur = kRefCamera;
         }
         const uint32_t n_need = count_mask(__ballot(tr.cur == kRefCamera) & __ballot(s >= s_last));
-        const uint32_t old_next = wave_next, old_avail = wave_end - wave_next, old_base = wave_base, old_origin = wave_origin;
+        const uint32_t old_next = wave_next, old_avail = wave_end - wave_next, old_base = wave_base, old_origin = wave_origin, old_slot = wave_slot;
         uint32_t new_first = 0;
         if (n_need > old_avail) {
           uint32_t b = 0;
@@ -296,6 +303,20 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
           wave_end = min(wave_base + min(c0 + P.batch_chunks, P.n_chunks) * 64u, P.n_units);
           wave_next = min(first + (n_need - old_avail), wave_end);
           new_first = first;
+          if (P.cuts) {
+            wave_slot = wave_serial % kCutRing;
+            ++wave_serial;
+            if (unit != kNoUnit && (unit >> kSlotShift) == wave_slot) unit |= kCutRing << kSlotShift;  // (kCutRing == 3: both bits set)
+            if (lane < kCutEntries) {
+              uint32_t e = t < P.n_tiles ? P.cuts[(size_t)t * kCutEntries + lane] : kRefDone;
+              if constexpr (kAllLds && !kWide)
+                if (!(e & kRefLeaf)) e = lds_node_address(tv.lnodes, e);
+              my_ring[wave_slot * kCutEntries + lane] = e;
+            }
+            // (the lanes read it back below and in later rounds: LDS operations of one wave complete in order)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
         } else {
           wave_next += n_need;
         }
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
                 chunk = ((rel >> 4) & 3u) | ((rel >> 8) << 2);
               }
               const uint32_t i = (origin & 0xffffu) + io, j = (origin >> 16) + jo;
-              unit = chunk;
+              unit = chunk | ((from_old ? old_slot : wave_slot) << kSlotShift);
               pij = i | (j << 16);
               acc = d3(0.0, 0.0, 0.0);
               if (i < P.x1 && j < P.y1) {
@@ -341,9 +362,22 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
             depth_left = P.cam.max_depth;
             trav_begin<kWide>(tr, tv, o, d, __builtin_inf(), empty_stack());
             {
-            const uint32_t first = trav_first<kAllLds>(tr, tv, t_min);
-            if (kProf) n_tests += first;
-          }
+              const uint32_t first = trav_first<kAllLds>(tr, tv, t_min);
+              if (kProf) n_tests += first;
+            }
+            if ((unit >> kSlotShift) < kCutRing) {  // the walk starts at the tile's entry list: the nearest entry now, the others set aside
+              const u32x4 e = *(lds_u32x4*)(my_ring + (unit >> kSlotShift) * kCutEntries);
+              tr.cur = e.x;
+              if constexpr (kWide) {
+                if (e.w != kRefDone) trav_push(tr, RTA_STACK, e.w);
+                if (e.z != kRefDone) trav_push(tr, RTA_STACK, e.z);
+                if (e.y != kRefDone) trav_push(tr, RTA_STACK, e.y);
+              } else {
+                if (e.w != kRefDone) trav_push(tr, RTA_STACK, stack_stride, e.w);
+                if (e.z != kRefDone) trav_push(tr, RTA_STACK, stack_stride, e.z);
+                if (e.y != kRefDone) trav_push(tr, RTA_STACK, stack_stride, e.y);
+              }
+            }
           }
         }
       }
@@ -577,7 +611,7 @@ hipError_t static_scratch(int device, void** ptr, size_t* bytes) {
 // --------------------------------------------------------------- launchers ----
 size_t lds_node_bytes() { return kLdsNodeQuads * 16; }
 size_t lds_wide_node_bytes() { return kWideLdsStride; }
-size_t lds_fixed_bytes() { return CAM_DOUBLES * 8 + kTrigEntries * 16 + 32; }  // camera constants, sin/cos table, the record of the sphere outside the tree
+size_t lds_fixed_bytes() { return CAM_DOUBLES * 8 + kTrigEntries * 16 + 32 + kRingWords * 4; }  // camera constants, sin/cos table, the record of the sphere outside the tree, the waves' entry lists
 size_t tree_lds_bytes(const SceneDev& sc) {
   if (sc.wide)
     return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * kWideLdsStride + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +

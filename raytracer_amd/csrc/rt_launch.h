@@ -38,6 +38,7 @@ struct SceneDev {
   // in LDS; the first lds_stack entries of a lane's stack live in LDS, the other stack_cap - lds_stack in gstack.
   uint32_t wide;
   uint32_t lds_stack;
+  uint32_t cut_k;           // entries of an entry list that stack_cap has room for (see launch_tile_cuts)
 };
 
 struct CameraDev {
@@ -66,6 +67,9 @@ struct RenderParams {
   uint32_t leaf_min;   // inside a run of inner-node rounds the leaf block runs as soon as this many lanes wait at leaves
   uint32_t both_min;   // when a traversal block (inner or leaf) is due, the other one runs too if this many lanes want it
   float time_scale;    // power of two that brings the times of the scene, seen from the camera, below 1 (0: from the scene's extent alone)
+  // Entry lists of the tiles (launch_tile_cuts), kCutEntries words per tile in the order the kernel numbers its tiles, or null:
+  // every camera ray then starts its walk at the root.
+  const uint32_t* cuts;
   double* out;
   unsigned long long* counters;  // see kRenderCounters
 };
@@ -83,6 +87,20 @@ size_t tree_lds_bytes(const SceneDev& sc);
 size_t lds_node_bytes();
 size_t lds_wide_node_bytes();
 size_t lds_fixed_bytes();
+
+// Entry lists ("cuts") for camera rays.  All camera rays of an 8x8 pixel tile lie in a thin beam around the ray from
+// the middle of the lens through the middle of the tile.  Before a render, launch_tile_cuts walks the tree once per tile
+// with that beam and records up to `k` inner nodes (kCutEntries words per tile, the nearest first, unused words
+// 0xffffffff) such that every sphere a camera ray of the tile can hit lies below one of them; the render kernel starts the
+// tile's camera rays at those nodes instead of at the root.  A walk that starts with k - 1 entries set aside needs up to
+// k - 2 more stack entries than a walk from the root.
+constexpr uint32_t kCutEntries = 4;
+constexpr uint32_t kCutRing = 3;  // tiles whose entry lists a wave keeps at hand (the current batch's and the two before it)
+// rho0: bound on the distance of a camera ray's origin from the lens centre; h_tile: bound on the distance of the point a
+// camera ray of the tile aims at from the tile's middle (both in scene units); tile t covers the pixels from
+// (x0 + (t % tiles_x) * 8, y0 + ((t / tiles_x) * row_stride + row_first) * 8).
+hipError_t launch_tile_cuts(const SceneDev& sc, const CameraDev& cam, double rho0, double h_tile, uint32_t x0, uint32_t y0, uint32_t tiles_x,
+                            uint32_t n_tiles, uint32_t row_first, uint32_t row_stride, uint32_t k, uint32_t* cuts, hipStream_t stream);
 
 // All launchers enqueue on `stream` and return the launch status; pointers are device pointers.
 hipError_t launch_trace_batch(const SceneDev& sc, const double* org, const double* dir, size_t n, double t_min, double t_max, int32_t* prim,
