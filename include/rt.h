@@ -256,15 +256,18 @@ int rt_render_multi(const rt_scene* scene, const rt_config* cfg, uint64_t seed, 
                     uint32_t partition, double* rgb_sum, rt_render_stats* stats);
 
 /* rt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The launch's counters and per-chunk
- * sums live in a 32 MiB static device array that every GPU the library runs on holds until the process ends; the
- * call makes no hipMalloc, hipFree, event or other allocating call.  The request is cut into chunks exactly as
- * rt_render_device cuts it, so the frame is bit for bit the same; a request whose per-chunk sums exceed the array
- * (n_chunks x pixels x 24 bytes > 32 MiB - 256; frames too large for that still fit when their sample range is
- * short enough to be one chunk) or whose tree needs traversal stacks in global memory is refused with
- * RT_ERR_LIMIT.  The kernels are enqueued on `stream`; with stats == NULL the call returns without waiting for
- * them, otherwise it waits and fills stats (kernel_ms stays 0: no events).  All calls on one GPU share that
- * GPU's array: calls that overlap in time on one GPU race. */
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The launch's counters, per-chunk
+ * sums, the traversal stacks' overflow columns (scenes walked through the four-wide tree: CUs x 4 KiB per stack
+ * entry beyond the eight kept in LDS) and the tiles' entry lists live in a 32 MiB static device array that every
+ * GPU the library runs on holds until the process ends; the call makes no hipMalloc, hipFree, event or other
+ * allocating call.  The request is cut into chunks exactly as rt_render_device cuts it, so the frame is bit for
+ * bit the same; a request whose per-chunk sums (n_chunks x pixels x 24 bytes; frames too large for that still
+ * fit when their sample range is short enough to be one chunk) and stack columns together exceed 32 MiB - 256 is
+ * refused with RT_ERR_LIMIT; entry lists that no longer fit are left out (same frame, rendered more slowly).  The
+ * kernels are enqueued on `stream`; with stats == NULL the call returns without waiting for them, otherwise it
+ * waits and fills stats (kernel_ms stays 0: no events).  All calls on one GPU share that GPU's array: calls that
+ * overlap in time on one GPU race (two calls without stats on different streams already do), and nothing detects
+ * it -- serialise them on one stream or wait in between. */
 int rt_render_device_noalloc(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
                              const rt_rect* tile, double* rgb_sum_dev, void* stream, rt_render_stats* stats);
 
@@ -275,10 +278,12 @@ int rt_render_device_noalloc(const rt_scene* scene, const rt_config* cfg, uint64
  * block is due, the other of the two runs as well if this many lanes want it), "chunk_spp", "target_units" and "batches_per_wave" (how a
  * call's sample range is cut into units of work), "quad_tiles" (1, the default: the 64 lanes of a wave start on a 4x4 block of
  * pixels in four chunks of the sample range instead of 8x8 pixels in one, when the number of chunks allows) -- none of these changes which
- * samples are rendered; "force_global_stack" (scenes created while it is 1 keep
- * their traversal stacks in global memory, the path trees deeper than 35 levels
- * take); "first_leaf" (1, the default: in scenes created while it is 1, a one-sphere leaf directly under the root of the
- * host-built tree is tested when a query starts and taken out of the walk; closest hits are the same); "force_staged_sum" (rt_render_multi adds sample-split frames through copies to the first
+ * samples are rendered; "tile_cuts" (longest entry list the camera rays of a tile start from, 0 .. 8; 0: every ray
+ * starts at the root; frames are the same for every value); "force_global_stack" (scenes created while it is 1 keep
+ * their traversal stacks in global memory, the path that trees too deep for per-lane stacks in LDS -- more than about
+ * 30 levels, see rt_scene_info.lds_bytes -- take); "first_leaf" (1, the default: in scenes created while it is 1, a
+ * one-sphere leaf in the top four levels of the tree, from either builder, whose box has at least half the tree's
+ * surface area is tested when a query starts and cut out of the device's copy of the tree; closest hits are the same); "force_staged_sum" (rt_render_multi adds sample-split frames through copies to the first
  * device even where peers can read each other).  inner_min and leaf_min must be whole numbers in 1 .. 64,
  * both_min in 0 .. 64; other values are refused.  The knobs are process-wide atomics: a render call reads them
  * once when it starts.  With RT_PROFILE_BLOCKS set in the environment, rt_render* runs the

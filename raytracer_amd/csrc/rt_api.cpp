@@ -105,7 +105,7 @@ std::atomic<uint32_t> g_chunk_spp{64};
 std::atomic<uint32_t> g_first_leaf{1};  // 0: keep a leaf under the root inside the walk (for measurements)
 std::atomic<uint32_t> g_quad_tiles{1};
 // Longest entry list a tile's camera rays start from (rt_launch.h); 0: every ray starts at the root.
-std::atomic<uint32_t> g_tile_cuts{kCutEntries};
+std::atomic<uint32_t> g_tile_cuts{kWideCutEntries};
 // Fewest units of work a call is cut into (32 per lane of the chip).
 std::atomic<uint64_t> g_target_units{1u << 25};
 std::atomic<uint64_t> g_batches_per_wave{64};
@@ -361,7 +361,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   // fit, the top of the tree, the sphere records, the slots' shading data and the materials.
   // A tree too deep for that keeps its stacks in global memory and LDS holds scene data only.
   const uint32_t depth = tree_depth ? tree_depth : 1;
-  const size_t reserve = lds_fixed_bytes() + 64;
+  const size_t reserve = lds_fixed_bytes(false) + 64;
   const bool stack_in_lds = depth <= max_depth && !g_force_global_stack.load();
   const size_t node_bytes = n_dev_nodes * sizeof(DevNode), sph_bytes = n * sizeof(DevSphere);
   const size_t aux_bytes = n * sizeof(DevSphereAux), mat_bytes = nm * 32, used_mat_bytes = n_used * 32;  // nm: records in the table
@@ -434,16 +434,16 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
       rp.d_nodes = d_wide;  // owned by the replica from here on, also if the call failed half-way
       RT_HIP(e);
       n_final_nodes = n_wide;
-      wide_stack_entries = 3 * levels + 1 + (kCutEntries - 2);  // at most three children set aside per level; a camera ray's entry list
+      wide_stack_entries = 3 * levels + 1 + (kWideCutEntries - 2);  // at most three children set aside per level; a camera ray's entry list
       wide_bound = tree.bound;
     } else {
       if (wide_cache->nodes.empty()) *wide_cache = collapse_wide(wide_peel ? host_nodes : flat.nodes.data(), n_dev_nodes, wide_peel ? walk_root : flat.root);
       n_final_nodes = wide_cache->nodes.size();
-      wide_stack_entries = wide_cache->stack_entries + (kCutEntries - 2);
+      wide_stack_entries = wide_cache->stack_entries + (kWideCutEntries - 2);
       wide_bound = std::fmax(wide_cache->bound, flat.bound);
     }
     lds_stack = g_force_global_stack.load() ? 0u : std::min<uint32_t>(wide_stack_entries, g_wide_lds_stack.load());
-    const size_t wide_room = kLdsPerCu - reserve - (size_t)lds_stack * kWorkgroup * 4;
+    const size_t wide_room = kLdsPerCu - (lds_fixed_bytes(true) + 64) - (size_t)lds_stack * kWorkgroup * 4;
     size_t wide_left = wide_room;
     n_nodes_lds = (uint32_t)std::min(n_final_nodes, wide_left / lds_wide_node_bytes());
     wide_left -= n_nodes_lds * lds_wide_node_bytes();
@@ -487,7 +487,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   dev.n_aux_lds = n_aux_lds;
   dev.n_materials_lds = n_mat_lds;
   dev.stack_cap = wide ? wide_stack_entries : depth + cut_rows;
-  dev.cut_k = wide ? kCutEntries : cut_rows + 2;
+  dev.cut_k = wide ? kWideCutEntries : cut_rows + 2;
   dev.stack_in_lds = wide ? 1u : (stack_in_lds ? 1u : 0u);
   dev.wide = wide ? 1u : 0u;
   dev.lds_stack = lds_stack;
@@ -626,7 +626,7 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
   // The tree: built on the host with the reference's algorithm (once, then uploaded to every device), or on each
   // device (two or more spheres; a tree too deep for the traversal stack falls back to the host builder).
   auto t0 = std::chrono::steady_clock::now();
-  const size_t max_depth = (kLdsPerCu - lds_fixed_bytes() - 64 - 16 * 1024) / (kWorkgroup * 4);
+  const size_t max_depth = (kLdsPerCu - lds_fixed_bytes(false) - 64 - 16 * 1024) / (kWorkgroup * 4);
   bool want_device = builder == RT_BUILD_DEVICE_LBVH && n >= 2;
   FlatBvh flat;
   WideBvh wide_cache;
@@ -857,12 +857,12 @@ int plan_render(const Replica& rp, const CameraDev& cam, uint64_t seed, const rt
   L->partial_bytes = P.direct ? 0 : (size_t)plan.n_chunks * tw * P.local_rows * 24;
   L->cut_k = std::min(g_tile_cuts.load(), rp.dev.cut_k);
   if (L->cut_k >= 1) {
-    // |dx U + dy V| for (dx, dy) in the unit disk, and |a du + b dv| for |a|, |b| <= 4 (the tile's middle to its edge)
+    // |dx U + dy V| for (dx, dy) in the unit disk, and |a du + b dv| for |a|, |b| <= 1/2
     auto dot3 = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
     const double uu = dot3(cam.disk_u, cam.disk_u), vv = dot3(cam.disk_v, cam.disk_v), uv = std::fabs(dot3(cam.disk_u, cam.disk_v));
     L->beam_rho0 = cam.defocus ? std::sqrt(std::max(uu, vv) + uv) * (1.0 + 1e-9) : 0.0;
-    L->beam_h = 4.0 * std::sqrt(dot3(cam.du, cam.du) + dot3(cam.dv, cam.dv) + 2.0 * std::fabs(dot3(cam.du, cam.dv))) * (1.0 + 1e-9);
-    L->cuts_bytes = (size_t)P.n_tiles * kCutEntries * 4;
+    L->beam_h = 0.5 * std::sqrt(dot3(cam.du, cam.du) + dot3(cam.dv, cam.dv) + 2.0 * std::fabs(dot3(cam.du, cam.dv))) * (1.0 + 1e-9);
+    L->cuts_bytes = (size_t)P.n_tiles * cut_tile_words(rp.dev.wide != 0u) * 4;
   }
   // One persistent workgroup per CU (fewer if there is less work than that).
   L->blocks = rp.num_cus;
@@ -1628,8 +1628,8 @@ int rt_debug_set(const char* name, double value) {
       return RT_OK;
     }
     if (key == "tile_cuts") {
-      if (!(value >= 0.0 && value <= (double)kCutEntries) || value != std::floor(value))
-        return fail(RT_ERR_INVALID, "rt_debug_set: tile_cuts must be a whole number in 0 .. " + std::to_string(kCutEntries));
+      if (!(value >= 0.0 && value <= (double)kWideCutEntries) || value != std::floor(value))
+        return fail(RT_ERR_INVALID, "rt_debug_set: tile_cuts must be a whole number in 0 .. " + std::to_string(kWideCutEntries));
       g_tile_cuts.store((uint32_t)value);
       return RT_OK;
     }

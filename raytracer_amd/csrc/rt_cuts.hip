@@ -95,21 +95,51 @@ struct Children<true> {
   }
 };
 
+// f32 not above / not below a double
+__device__ __forceinline__ float f32_down(double v) {
+  float f = (float)v;
+  return (double)f > v ? nextafterf(f, -__builtin_inff()) : f;
+}
+__device__ __forceinline__ float f32_up(double v) {
+  float f = (float)v;
+  return (double)f < v ? nextafterf(f, __builtin_inff()) : f;
+}
+
 template <bool kWide>
-__global__ __launch_bounds__(64) void tile_cuts_kernel(SceneDev sc, CameraDev cam, double rho0, double h_tile, uint32_t x0, uint32_t y0,
+__global__ __launch_bounds__(64) void tile_cuts_kernel(SceneDev sc, CameraDev cam, double rho0, double h_pixel, uint32_t x0, uint32_t y0,
                                                        uint32_t tiles_x, uint32_t n_tiles, uint32_t row_first, uint32_t row_stride, uint32_t k_max,
                                                        uint32_t* __restrict__ cuts) {
+  constexpr uint32_t kSide = 8u, kEntries = cut_entries(kWide), kWords = cut_entry_words(kWide);
+  constexpr int kKids = Children<kWide>::kCount;
   const uint32_t t = blockIdx.x * 64u + threadIdx.x;
   if (t >= n_tiles) return;
-  uint32_t out[kCutEntries];
-  for (uint32_t k = 0; k < kCutEntries; ++k) out[k] = kRefNone;
+  const double h_tile = h_pixel * (double)kSide;  // from the middle of the tile to its corners
+  struct Entry {
+    uint32_t ref;
+    float lo[3], hi[3];
+  };
+  Entry out[kEntries];
   uint32_t n_out = 0;
   auto write = [&]() {
-    for (uint32_t k = 0; k < kCutEntries; ++k) cuts[(size_t)t * kCutEntries + k] = out[k];
+    uint32_t* dst = cuts + (size_t)t * (kEntries * kWords);
+    for (uint32_t k = 0; k < kEntries; ++k) {
+      const bool used = k < n_out;
+      dst[k * kWords] = used ? out[k].ref : kRefNone;
+      if constexpr (kWords == 8u) {
+        for (int a = 0; a < 3; ++a) {
+          dst[k * kWords + 1 + a] = __float_as_uint(used ? out[k].lo[a] : 0.0f);
+          dst[k * kWords + 4 + a] = __float_as_uint(used ? out[k].hi[a] : 0.0f);
+        }
+        dst[k * kWords + 7] = 0u;
+      }
+    }
   };
   const uint32_t root = sc.root;
+  Entry whole;  // the root with a box that holds everything
+  whole.ref = root;
+  for (int a = 0; a < 3; ++a) whole.lo[a] = -3.0e38f, whole.hi[a] = 3.0e38f;
   if (root == kRefNone || (root & kRefLeaf) || k_max < 1u) {  // no tree to speak of: the walk starts where it always did
-    out[0] = root;
+    if (root != kRefNone) out[n_out++] = whole;
     write();
     return;
   }
@@ -117,11 +147,12 @@ __global__ __launch_bounds__(64) void tile_cuts_kernel(SceneDev sc, CameraDev ca
   Children<kWide> ch;
   ch.load(sc, root);
   double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
-  for (int c = 0; c < Children<kWide>::kCount; ++c)
+  for (int c = 0; c < kKids; ++c)
     if (ch.ref[c] != kRefNone)
       for (int k = 0; k < 3; ++k) blo[k] = fmin(blo[k], (double)ch.lo[c][k]), bhi[k] = fmax(bhi[k], (double)ch.hi[c][k]);
   const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
-  const double fx = (double)(x0 + tx * 8u) + 3.5, fy = (double)(y0 + (ty * row_stride + row_first) * 8u) + 3.5;
+  const double half = 0.5 * (double)(kSide - 1u);
+  const double fx = (double)(x0 + tx * 8u) + half, fy = (double)(y0 + (ty * row_stride + row_first) * 8u) + half;
   Beam b;
   b.c = V3{cam.center[0], cam.center[1], cam.center[2]};
   const V3 m = {cam.pixel00[0] + fx * cam.du[0] + fy * cam.dv[0], cam.pixel00[1] + fx * cam.du[1] + fy * cam.dv[1],
@@ -140,7 +171,7 @@ __global__ __launch_bounds__(64) void tile_cuts_kernel(SceneDev sc, CameraDev ca
   const double mx = 0.5 * (bhi[0] + blo[0]) - b.c.x, my = 0.5 * (bhi[1] + blo[1]) - b.c.y, mz = 0.5 * (bhi[2] + blo[2]) - b.c.z;
   const double reach = sqrt(mx * mx + my * my + mz * mz) + sqrt(ex * ex + ey * ey + ez * ez);
   if (!(len > 0.0) || !(g < 0.5) || !(reach < 1e300)) {  // a lens or tile as wide as the focus distance: no beam worth the name
-    out[0] = root;
+    out[n_out++] = whole;
     write();
     return;
   }
@@ -149,19 +180,20 @@ __global__ __launch_bounds__(64) void tile_cuts_kernel(SceneDev sc, CameraDev ca
 
   // Depth-first, nearest child first.  A node whose children the beam touches is opened if all of them are inner nodes and
   // the list has room for them; else it goes on the list itself.  (Entries are inner nodes: a ray tests a leaf's box at
-  // the leaf's parent before it tests the sphere.)  Entries listed and nodes waiting never exceed k_max together.
-  const uint32_t K = k_max < kCutEntries ? k_max : kCutEntries;
-  uint32_t stack[kCutEntries];
+  // the leaf's parent before it tests the sphere.)  Entries listed and nodes waiting never exceed K together.
+  const uint32_t K = k_max < kEntries ? k_max : kEntries;
+  Entry stack[kEntries];
   uint32_t n_st = 0;
-  stack[n_st++] = root;
+  for (int a = 0; a < 3; ++a) whole.lo[a] = f32_down(blo[a]), whole.hi[a] = f32_up(bhi[a]);
+  stack[n_st++] = whole;
   while (n_st > 0) {
-    const uint32_t node = stack[--n_st];
-    if (node != root) ch.load(sc, node);
-    bool hit[Children<kWide>::kCount];
-    double tn[Children<kWide>::kCount];
+    const Entry node = stack[--n_st];
+    if (node.ref != root) ch.load(sc, node.ref);
+    bool hit[kKids];
+    double tn[kKids];
     uint32_t kids = 0;
     bool any_leaf = false;
-    for (int c = 0; c < Children<kWide>::kCount; ++c) {
+    for (int c = 0; c < kKids; ++c) {
       tn[c] = 0.0;
       hit[c] = ch.ref[c] != kRefNone && beam_box(b, ch.lo[c], ch.hi[c], tn[c]);
       if (hit[c]) {
@@ -176,10 +208,13 @@ __global__ __launch_bounds__(64) void tile_cuts_kernel(SceneDev sc, CameraDev ca
     }
     for (uint32_t n = 0; n < kids; ++n) {  // the farthest first, so that the nearest is taken off first
       int far = -1;
-      for (int c = 0; c < Children<kWide>::kCount; ++c)
+      for (int c = 0; c < kKids; ++c)
         if (hit[c] && (far < 0 || tn[c] > tn[far])) far = c;
       hit[far] = false;
-      stack[n_st++] = ch.ref[far];
+      Entry e;
+      e.ref = ch.ref[far];
+      for (int a = 0; a < 3; ++a) e.lo[a] = ch.lo[far][a], e.hi[a] = ch.hi[far][a];
+      stack[n_st++] = e;
     }
   }
   write();

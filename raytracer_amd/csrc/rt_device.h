@@ -978,7 +978,9 @@ struct LdsImage {
   lds_u32* ring;  // per wave kCutRing entry lists of kCutEntries words (see rt_launch.h)
   lds_u32* stack_base;
 };
-constexpr uint32_t kRingWords = (kWorkgroup / 64u) * kCutRing * kCutEntries;
+// words of a wave's ring of entry lists, and of a workgroup's
+constexpr uint32_t ring_words_per_wave(bool wide) { return kCutRing * cut_tile_words(wide); }
+constexpr uint32_t ring_words(bool wide) { return (kWorkgroup / 64u) * ring_words_per_wave(wide); }
 
 // `t_min`: where the intervals of the kernel's queries start; `time_scale`: see TimeFrame (0: from the scene's extent).
 template <bool kAllLds, bool kWide = false>
@@ -988,7 +990,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
   lds_double* ltrig = lcam + CAM_DOUBLES;
   lds_double2* lfirst = (lds_double2*)(ltrig + 2 * kTrigEntries);
   lds_u32* ring = (lds_u32*)(lfirst + 2);
-  lds_float4* lnodes = (lds_float4*)(ring + kRingWords);
+  lds_float4* lnodes = (lds_float4*)(ring + ring_words(kWide));
   lds_double2* lsph = (lds_double2*)(lnodes + (kWide ? kWideLdsStride / 16 : kLdsNodeQuads) * sc.n_nodes_lds);
   lds_double2* laux = lsph + 2 * sc.n_spheres_lds;
   lds_double2* lmat = laux + sc.n_aux_lds;
@@ -1009,7 +1011,7 @@ __device__ __forceinline__ LdsImage stage_scene(const SceneDev& sc, const Camera
     ltrig[2 * i] = sn;
     ltrig[2 * i + 1] = cs;
   }
-  for (uint32_t i = threadIdx.x; i < kRingWords; i += wg) ring[i] = kRefDone;
+  for (uint32_t i = threadIdx.x; i < ring_words(kWide); i += wg) ring[i] = kRefDone;
   if (kWide) {  // four-wide nodes are staged as they are, 80 bytes apart
     for (uint32_t i = threadIdx.x; i < kWideStagedQuads * sc.n_nodes_lds; i += wg) {
       const uint32_t node = i / kWideStagedQuads, quad = i - node * kWideStagedQuads;

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
   // still at work on a unit when the wave's ring comes round to that unit's place loses its list and starts its
   // remaining camera rays at the root.
   constexpr uint32_t kUnitChunk = 0x3fffffffu, kSlotShift = 30u;
-  lds_u32* const my_ring = im.ring + (threadIdx.x >> 6) * (kCutRing * kCutEntries);
+  constexpr uint32_t kSlotWords = cut_tile_words(kWide);  // a batch's lists
+  lds_u32* const my_ring = im.ring + (threadIdx.x >> 6) * ring_words_per_wave(kWide);
   uint32_t wave_slot = kCutRing, wave_serial = 0;  // the ring place of the wave's current batch; batches taken so far
 
   // A unit of work is one pixel's samples of one chunk of the sample range.  A wave takes a batch
@@ -307,11 +308,11 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
             wave_slot = wave_serial % kCutRing;
             ++wave_serial;
             if (unit != kNoUnit && (unit >> kSlotShift) == wave_slot) unit |= kCutRing << kSlotShift;  // (kCutRing == 3: both bits set)
-            if (lane < kCutEntries) {
-              uint32_t e = t < P.n_tiles ? P.cuts[(size_t)t * kCutEntries + lane] : kRefDone;
+            for (uint32_t w = lane; w < kSlotWords; w += 64u) {
+              uint32_t e = t < P.n_tiles ? P.cuts[(size_t)t * kSlotWords + w] : kRefDone;
               if constexpr (kAllLds && !kWide)
                 if (!(e & kRefLeaf)) e = lds_node_address(tv.lnodes, e);
-              my_ring[wave_slot * kCutEntries + lane] = e;
+              my_ring[wave_slot * kSlotWords + w] = e;
             }
             // (the lanes read it back below and in later rounds: LDS operations of one wave complete in order)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -366,13 +367,23 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
               if (kProf) n_tests += first;
             }
             if ((unit >> kSlotShift) < kCutRing) {  // the walk starts at the tile's entry list: the nearest entry now, the others set aside
-              const u32x4 e = *(lds_u32x4*)(my_ring + (unit >> kSlotShift) * kCutEntries);
-              tr.cur = e.x;
+              const lds_u32* list = my_ring + (unit >> kSlotShift) * kSlotWords;
               if constexpr (kWide) {
-                if (e.w != kRefDone) trav_push(tr, RTA_STACK, e.w);
-                if (e.z != kRefDone) trav_push(tr, RTA_STACK, e.z);
-                if (e.y != kRefDone) trav_push(tr, RTA_STACK, e.y);
+                // the entries whose own box the ray can hit are set aside, the farthest first; then the nearest is taken up
+                tr.cur = kRefDone;
+#pragma unroll
+                for (int k = (int)kWideCutEntries - 1; k >= 0; --k) {
+                  const u32x4 a = *(const lds_u32x4*)(list + 8 * k);
+                  const f32x4 hi = *(const lds_float4*)(list + 8 * k + 4);
+                  float tn;
+                  if (a.x != kRefDone && box_test(tr.q, f32x2{__uint_as_float(a.y), hi.x}, f32x2{__uint_as_float(a.z), hi.y},
+                                                  f32x2{__uint_as_float(a.w), hi.z}, 0.0f, tr.tmaxf, tn))
+                    trav_push(tr, RTA_STACK, a.x);
+                }
+                trav_pop(tr, RTA_STACK, 0u);
               } else {
+                const u32x4 e = *(const lds_u32x4*)list;
+                tr.cur = e.x;
                 if (e.w != kRefDone) trav_push(tr, RTA_STACK, stack_stride, e.w);
                 if (e.z != kRefDone) trav_push(tr, RTA_STACK, stack_stride, e.z);
                 if (e.y != kRefDone) trav_push(tr, RTA_STACK, stack_stride, e.y);
@@ -611,12 +622,12 @@ hipError_t static_scratch(int device, void** ptr, size_t* bytes) {
 // --------------------------------------------------------------- launchers ----
 size_t lds_node_bytes() { return kLdsNodeQuads * 16; }
 size_t lds_wide_node_bytes() { return kWideLdsStride; }
-size_t lds_fixed_bytes() { return CAM_DOUBLES * 8 + kTrigEntries * 16 + 32 + kRingWords * 4; }  // camera constants, sin/cos table, the record of the sphere outside the tree, the waves' entry lists
+size_t lds_fixed_bytes(bool wide) { return CAM_DOUBLES * 8 + kTrigEntries * 16 + 32 + ring_words(wide) * 4; }  // camera constants, sin/cos table, the record of the sphere outside the tree, the waves' entry lists
 size_t tree_lds_bytes(const SceneDev& sc) {
   if (sc.wide)
-    return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * kWideLdsStride + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
+    return lds_fixed_bytes(true) + (size_t)sc.n_nodes_lds * kWideLdsStride + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
            (size_t)sc.n_materials_lds * 32 + (size_t)sc.lds_stack * kWorkgroup * 4;
-  return lds_fixed_bytes() + (size_t)sc.n_nodes_lds * lds_node_bytes() + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
+  return lds_fixed_bytes(false) + (size_t)sc.n_nodes_lds * lds_node_bytes() + (size_t)sc.n_spheres_lds * 32 + (size_t)sc.n_aux_lds * 16 +
          (size_t)sc.n_materials_lds * 32 + (sc.stack_in_lds ? (size_t)(sc.stack_cap + kStackSpareRows) * kWorkgroup * 4 : 0);
 }
 

@@ -83,10 +83,10 @@ constexpr uint32_t kStackSpareRows = 1;
 
 // Dynamic LDS a tree-walking kernel needs for this scene (includes the camera block).
 size_t tree_lds_bytes(const SceneDev& sc);
-// LDS footprint of one staged node / of the fixed part (camera constants).
+// LDS footprint of one staged node / of the fixed part (camera constants, tables, the waves' entry lists: more of those for the four-wide walk).
 size_t lds_node_bytes();
 size_t lds_wide_node_bytes();
-size_t lds_fixed_bytes();
+size_t lds_fixed_bytes(bool wide);
 
 // Entry lists ("cuts") for camera rays.  All camera rays of an 8x8 pixel tile lie in a thin beam around the ray from
 // the middle of the lens through the middle of the tile.  Before a render, launch_tile_cuts walks the tree once per tile
@@ -96,10 +96,21 @@ size_t lds_fixed_bytes();
 // k - 2 more stack entries than a walk from the root.
 constexpr uint32_t kCutEntries = 4;
 constexpr uint32_t kCutRing = 3;  // tiles whose entry lists a wave keeps at hand (the current batch's and the two before it)
-// rho0: bound on the distance of a camera ray's origin from the lens centre; h_tile: bound on the distance of the point a
-// camera ray of the tile aims at from the tile's middle (both in scene units); tile t covers the pixels from
+// Scenes walked through the four-wide tree (where a node step costs a trip to L1 or L2) get longer lists whose entries
+// carry the node's own box, 8 words each: ref, box low xyz, box high xyz (f32, rounded outwards), 0.  A camera ray tests
+// the boxes when it starts and sets aside only the entries it can hit.  (Measured on 10^4 .. 10^6 spheres: lists of 6 and
+// of 12 within 1.5 % of 8; a list per quarter of a tile, which takes four times the LDS, 1 - 7 % slower.)
+#ifndef RTA_WIDE_CUT_ENTRIES  // (overridden by tools/build_variant.sh for measurements)
+#define RTA_WIDE_CUT_ENTRIES 8
+#endif
+constexpr uint32_t kWideCutEntries = RTA_WIDE_CUT_ENTRIES;
+constexpr uint32_t cut_entries(bool wide) { return wide ? kWideCutEntries : kCutEntries; }
+constexpr uint32_t cut_entry_words(bool wide) { return wide ? 8u : 1u; }
+constexpr uint32_t cut_tile_words(bool wide) { return cut_entries(wide) * cut_entry_words(wide); }  // what launch_tile_cuts writes per tile
+// rho0: bound on the distance of a camera ray's origin from the lens centre; h_pixel: bound on the distance between two
+// points of the focus plane that lie half a pixel apart in each direction (scene units); tile t covers the pixels from
 // (x0 + (t % tiles_x) * 8, y0 + ((t / tiles_x) * row_stride + row_first) * 8).
-hipError_t launch_tile_cuts(const SceneDev& sc, const CameraDev& cam, double rho0, double h_tile, uint32_t x0, uint32_t y0, uint32_t tiles_x,
+hipError_t launch_tile_cuts(const SceneDev& sc, const CameraDev& cam, double rho0, double h_pixel, uint32_t x0, uint32_t y0, uint32_t tiles_x,
                             uint32_t n_tiles, uint32_t row_first, uint32_t row_stride, uint32_t k, uint32_t* cuts, hipStream_t stream);
 
 // All launchers enqueue on `stream` and return the launch status; pointers are device pointers.

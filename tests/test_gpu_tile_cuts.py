@@ -17,11 +17,11 @@ def _set(name, value):
 def _both_ways(world, cam, **kw):
     out = []
     try:
-        for k in (0.0, 4.0, 2.0):
+        for k in (0.0, 8.0, 3.0):
             _set(b"tile_cuts", k)
             out.append(cam.render_sum(world, **kw))
     finally:
-        _set(b"tile_cuts", 4.0)
+        _set(b"tile_cuts", 8.0)
     return out
 
 

@@ -20,10 +20,10 @@ def test_no_alloc_entry_point_matches_the_allocating_one():
         got = want.clone()
         torch.cuda.synchronize()
         st = cam.render_device(world, want.data_ptr(), seed=seed, tile=tile)
-        assert st["launches"] == 2  # chunked: the per-chunk sums are in use
+        assert st["launches"] == 3  # the tiles' entry lists, the render, the sum over chunks: the per-chunk sums are in use
         st2 = cam.render_device_noalloc(world, got.data_ptr(), seed=seed, tile=tile)
         torch.cuda.synchronize()
-        assert st2["rays"] == st["rays"] and st2["samples"] == st["samples"] and st2["launches"] == 2
+        assert st2["rays"] == st["rays"] and st2["samples"] == st["samples"] and st2["launches"] == 3
         assert torch.equal(got, want)  # bit for bit: both cut the request into the same chunks
         assert float((want - 0.5).abs().max().item()) > 0.1
     # without stats the call only enqueues; the caller waits for the stream
@@ -51,5 +51,32 @@ def test_no_alloc_entry_point_matches_the_allocating_one():
     s1 = one.render_device(world, d.data_ptr(), seed=8)
     s2 = one.render_device_noalloc(world, e2.data_ptr(), seed=8)
     torch.cuda.synchronize()
-    assert s1["launches"] == 1 and s2["launches"] == 1 and torch.equal(d, e2)
+    assert s1["launches"] == 2 and s2["launches"] == 2 and torch.equal(d, e2)
+    world.close()
+
+
+def test_no_alloc_entry_point_on_a_scene_walked_through_the_four_wide_tree():
+    # the traversal stacks' overflow columns and the entry lists are carved out of the static array behind the per-chunk sums
+    import torch
+
+    n = 60000
+    world = rt.BVH(*rt.scene_field(7, n, 0.3, 0.3, 0.5))
+    info = world.info()
+    assert info["n_nodes_in_lds"] < info["n_device_nodes"]
+    for width, spp, seed in ((160, 16, 5), (96, 6, 6)):
+        cam = rt.config_field(n, width, spp, 30).camera()
+        want = torch.zeros((cam.image_height, width, 3), dtype=torch.float64, device="cuda")
+        got = torch.zeros_like(want)
+        torch.cuda.synchronize()
+        st = cam.render_device(world, want.data_ptr(), seed=seed)
+        st2 = cam.render_device_noalloc(world, got.data_ptr(), seed=seed)
+        torch.cuda.synchronize()
+        assert st2["rays"] == st["rays"] and st2["launches"] == st["launches"] == 3
+        assert torch.equal(got, want) and bool(want.any().item())
+    # a frame whose per-chunk sums leave no room for the stacks is refused
+    cam = rt.config_field(n, 640, 64, 30).camera()
+    c = torch.zeros((cam.image_height, 640, 3), dtype=torch.float64, device="cuda")
+    with pytest.raises(rt.RtError) as e:
+        cam.render_device_noalloc(world, c.data_ptr(), seed=1)
+    assert e.value.code == 4 and "static workspace holds" in str(e.value)
     world.close()

@@ -44,7 +44,7 @@ def main():
             sums[k] = float(frame.sum().item())
             print(json.dumps({"config": name, "tile_cuts": k, "Mrays_per_s": st["rays"] / st["kernel_ms"] / 1e3, "render_ms": st["kernel_ms"], "rays": st["rays"],
                               "node_steps": st["node_steps"], "same_sum_as_first": sums[k] == list(sums.values())[0]}), flush=True)
-        rt._lib.check(L.rt_debug_set(b"tile_cuts", C.c_double(4)))
+        rt._lib.check(L.rt_debug_set(b"tile_cuts", C.c_double(8)))
         world.close()
         del frame
 
