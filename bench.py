@@ -84,18 +84,86 @@ def cpu_baseline(spheres, materials, seconds_target=15.0):
     }
 
 
+def source_hash():
+    """A hash of the sources the library is built from: counter profiles carry it (tools/publish_profiles.sh), and a
+    profile whose hash differs from the tree's was measured on other kernels."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "raytracer_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic():
     """HBM bytes per launch of the default workload from the newest committed counter profile (a separate rocprofv3
-    --pmc run of this same command; counters cannot be collected from inside the timed run), or None."""
-    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
+    --pmc run of this same command; counters cannot be collected from inside the timed run), or None.  `stale` says
+    whether the profile was taken on other sources than the tree's."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
         try:
             out = json.load(open(path))
-            out["file"] = "profiles/" + name
-            return out
         except (OSError, ValueError):
             continue
+        out["file"] = "profiles/" + os.path.basename(path)
+        out["stale"] = out.get("source_hash") != source_hash()
+        return out
     return None
+
+
+# The reference traversal's node visits and sphere tests per ray on each configuration (CPU oracle, 160-pixel-wide frame,
+# 2 spp, render seed 12345: tools/run_configs.py --rooflines, profiles/r02_config_rooflines.jsonl).  Scenes and cameras
+# are seeded, so these do not change from run to run; the 10^6-sphere oracle tree takes 78 s to build, too long for a bench run.
+ORACLE_COUNTS = {
+    "c1": (22.578, 1.522), "c2": (22.578, 1.522), "c5": (26.170, 1.505), "c3": (33.729, 1.460), "c4": (46.954, 1.326),
+}
+# name: (spheres, p_lambertian, p_metal, max_fuzz, width, spp, depth, scene seed) -- the sizes the survey's measurement row states
+OTHER_CONFIGS = {
+    "c1": (None, 0, 0, 0, 830, 750, 50, 1),
+    "c5": (10000, 0.0, 0.5, 0.3, 3840, 128, 200, 5),
+    "c3": (100000, 1 / 3, 1 / 3, 1.0, 3840, 64, 50, 3),
+    "c4": (1000000, 0.15, 0.15, 1.0, 7680, 32, 50, 4),
+}
+
+
+def other_configs(rt, torch):
+    """One render of each of the other configurations (outside the timed region), each after a one-sample launch."""
+    out = []
+    for name, (n, pl, pm, fz, width, spp, depth, seed) in OTHER_CONFIGS.items():
+        if n is None:
+            spheres, materials = rt.scene_rtiow(seed)
+            cfg = rt.config_rtiow(width, spp, depth)
+        else:
+            spheres, materials = rt.scene_field(seed, n, pl, pm, fz)
+            cfg = rt.config_field(n, width, spp, depth)
+        world = rt.BVH(spheres, materials)
+        cam = cfg.camera()
+        frame = torch.zeros((cam.image_height, width, 3), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        cam.render_device(world, frame.data_ptr(), seed=1, spp_begin=0, spp_end=1)
+        frame.zero_()
+        torch.cuda.synchronize()
+        st = cam.render_device(world, frame.data_ptr(), seed=12345)
+        torch.cuda.synchronize()
+        info = world.info()
+        v, p = ORACLE_COUNTS[name]
+        rate = st["rays"] / (st["kernel_ms"] * 1e-3)
+        out.append({
+            "name": name,
+            "workload": "%d spheres, %dx%d, %d spp, max depth %d" % (len(spheres), width, cam.image_height, spp, depth),
+            "Mrays_per_s": rate / 1e6, "kernel_ms": st["kernel_ms"], "rays": st["rays"], "mean_path_length": st["rays"] / float(st["samples"]),
+            "node_visits_per_ray": v, "sphere_tests_per_ray": p, "flops_per_ray": flops_per_ray(v, p),
+            "frac": rate * flops_per_ray(v, p) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+            "build_ms": info["build_ms"], "walk": "two-wide tree in LDS" if info["n_nodes_in_lds"] == info["n_device_nodes"] else "four-wide tree, top in LDS",
+            "frame_mean_radiance": float(frame.mean().item()) / spp,
+        })
+        world.close()
+        del frame
+    return out
 
 
 def main():
@@ -108,6 +176,7 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--partition", choices=["samples", "tiles"], default="samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the one render each of the other configurations after the timed region")
     ap.add_argument("--force-distributed", action="store_true", help="set up the process group and run the collectives even with one rank (a rehearsal of the N > 1 path on one GPU)")
     args = ap.parse_args()
 
@@ -121,7 +190,7 @@ def main():
     import torch.distributed as dist
 
     import raytracer_amd as rt
-    from raytracer_amd.parallel import render_sample_split
+    from raytracer_amd.parallel import partition_samples
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -145,28 +214,38 @@ def main():
     cam = cfg.camera()
     w, h = args.width, cam.image_height
     frame = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    # The library renders on its own runtime's default stream (stream=None): a handle of torch's runtime means nothing to it.
+    # torch.cuda.synchronize() on both sides of a step orders the two.
     weak = args.partition == "samples"
     total_spp = args.spp * world_size if weak else args.spp
-    last = {"rays": 0, "ms": 0.0, "launches": 0}
+    last = {"rays": 0, "ms": 0.0, "launches": 0, "reduce_ms": 0.0}
 
     def render(s0, s1, tile):
-        st = cam.render_device(world, frame.data_ptr(), seed=12345, spp_begin=s0, spp_end=s1, tile=tile, stream=stream)
+        st = cam.render_device(world, frame.data_ptr(), seed=12345, spp_begin=s0, spp_end=s1, tile=tile)
         last["rays"] += st["rays"]
         last["ms"] += st["kernel_ms"]
         last["launches"] += 1
+
+    def timed_reduce():  # the collective of the sample split, with its own clock
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        last["reduce_ms"] += 1e3 * (time.perf_counter() - t)
 
     def step():
         frame.zero_()
         torch.cuda.synchronize()  # torch's stream and the library's are not ordered with each other
         if weak:
-            render_sample_split(render, frame, 0, total_spp, rank, world_size)
-            if args.force_distributed and world_size == 1:
-                dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)  # the collective of the N > 1 path, on one rank
+            # as raytracer_amd.parallel.render_sample_split does, with the reduce under its own clock
+            s0, s1 = partition_samples(0, total_spp, world_size)[rank]
+            render(s0, s1, None)
+            if distributed:
+                timed_reduce()
         else:
             # one launch per rank: the rank's tile rows of the whole frame (dealt round-robin), as rt_render_multi does
             shard = cam.partition(world_size, rt.PARTITION_TILES, spp_begin=0, spp_end=total_spp)[rank]
-            st = cam.render_shard_device(world, frame.data_ptr(), shard, seed=12345, stream=stream)
+            st = cam.render_shard_device(world, frame.data_ptr(), shard, seed=12345)
             last["rays"] += st["rays"]
             last["ms"] += st["kernel_ms"]
             last["launches"] += 1
@@ -187,12 +266,24 @@ def main():
     elapsed = time.perf_counter() - t0
     rays, kernel_ms, launches = last["rays"], last["ms"], last["launches"]
 
+    ranks = None
     if distributed:
         tot = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         total_rays, elapsed_max = tot.item(), tmax.item()
+        # what each rank ran on and how long its own kernels and reduces took: the first run on several GPUs must explain itself
+        prop = torch.cuda.get_device_properties(local_rank)
+        mine = {
+            "rank": rank, "local_rank": local_rank, "hip_ordinal_torch": torch.cuda.current_device(), "hip_ordinal_library": rt.get_device(),
+            "device": prop.name, "pci": "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0), getattr(prop, "pci_device_id", 0)),
+            "visible_devices": torch.cuda.device_count(), "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"),
+            "kernel_ms_per_step": kernel_ms / max(1, args.steps), "reduce_ms_per_step": last["reduce_ms"] / max(1, args.steps),
+            "rays_per_step": rays / max(1, args.steps), "elapsed_s": elapsed,
+        }
+        ranks = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks, mine)
     else:
         total_rays, elapsed_max = float(rays), elapsed
 
@@ -219,6 +310,10 @@ def main():
                 "frame_mean_radiance": float(frame.mean().item()) / total_spp if rank == 0 else None,
             },
         }
+        if ranks is not None:
+            out["ranks_seen"] = dist.get_world_size()
+            out["ranks"] = ranks
+            out["distinct_devices"] = len({r["pci"] for r in ranks})
         v_bar, p_bar, source = 22.61, 1.52, "oracle counts of an earlier run (seed 12345, 830x466)"
         if world_size == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(spheres, materials)
@@ -248,6 +343,8 @@ def main():
             "frac_meaning": "the reference's algorithmic flops per second over the FP32 vector peak",
             "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
             "traffic_replayed_from": traffic["file"] if traffic else None,
+            "traffic_stale": traffic["stale"] if traffic else None,
+            "source_hash": source_hash(),
             "kernel_ms": k_ms,
             "flops_per_ray": flops_per_ray(v_bar, p_bar),
             "per_ray_counts_from": source,
@@ -262,9 +359,10 @@ def main():
             "hbm_peak_GBs": HBM_PEAK_GBS,
             "note": "the whole scene (nodes, spheres, materials: 93 KB) lives in LDS, so neither HBM nor MFMA binds; "
                     "the kernel is bound by vector-ALU issue.  traffic and issue are not measured in this run: they are "
-                    "replayed from the committed rocprofv3 --pmc profile of this same command (traffic_replayed_from)",
+                    "replayed from the committed rocprofv3 --pmc profile of this same command (traffic_replayed_from; traffic_stale "
+                    "says whether that profile was taken on the sources this run was built from)",
         }
-        if traffic and "issue" in traffic:  # counter profile of the same workload: how busy the vector units are
+        if traffic and "issue" in traffic and not traffic["stale"]:  # counter profile of the same workload and sources: how busy the vector units are
             issue = traffic["issue"]
             out["roofline"]["issue"] = {
                 "valu_wave_instructions_per_launch": issue["valu_wave_instructions_per_launch"],
@@ -273,6 +371,15 @@ def main():
                 "measured_cycles_per_instruction_alone": "2.5-2.7 (f32 add, mul, fma; 32-bit add, logic, mov), 4.1-4.6 (min/max, compare, select, shift, f64)",
                 "replayed_from": traffic["file"] + ", profiles/r02_valu_rate.txt, profiles/r02_bank_rate.txt",
             }
+        if world_size == 1 and not args.no_other_configs:
+            head = {
+                "name": "c2", "workload": "488 spheres, %dx%d, %d spp, max depth %d (the timed headline above)" % (w, h, args.spp, args.depth),
+                "Mrays_per_s": rays_per_launch / (k_ms * 1e-3) / 1e6, "kernel_ms": k_ms, "rays": rays_per_launch,
+                "mean_path_length": out["config"]["mean_path_length"], "node_visits_per_ray": v_bar, "sphere_tests_per_ray": p_bar,
+                "flops_per_ray": flops_per_ray(v_bar, p_bar), "frac": out["roofline"]["frac"], "build_ms": world.info()["build_ms"],
+                "walk": "two-wide tree in LDS", "frame_mean_radiance": out["config"]["frame_mean_radiance"],
+            }
+            out["configs"] = [head] + other_configs(rt, torch)
         sys.stdout.flush()
         os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)

@@ -3,7 +3,12 @@
 tools/refresh_profiles.sh:  python tools/make_hbm_traffic.py gpurun_out/refresh_r02 > profiles/r02_hbm_traffic.json"""
 import json
 import os
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import source_hash
 
 d = json.load(open(os.path.join(sys.argv[1], "pmc_summary.json")))
 r = json.load(open(os.path.join(sys.argv[1], "pmc_summary_reduce_chunks.json")))
@@ -12,6 +17,9 @@ fetch_kb, write_kb = g(d, "FETCH_SIZE"), g(d, "WRITE_SIZE")
 waves = g(d, "SQ_WAVES")
 simd_cycles = g(d, "SQ_WAVE_CYCLES") * 4.0 / waves  # SQ_WAVE_CYCLES counts in units of 4 cycles, summed over the waves (4 per SIMD)
 out = {
+    # what the counters were taken on: bench.py compares source_hash with the tree's and marks the replayed figures stale if they differ
+    "source_hash": source_hash(),
+    "git_head": subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
     "kernel": "render_kernel<true,false,false,true,false>",
     "workload": "3840x2160, 1000 spp in 16 chunks, depth 50, 488 spheres; one launch (bench.py --steps 1 --warmup 0)",
     "FETCH_SIZE_KB_raw": fetch_kb,

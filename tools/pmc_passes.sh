@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 run_pass() {
   name=$1; shift
   counters=$1; shift
-  timeout -s KILL 180 rocprofv3 --pmc $counters --output-format csv -d "$OUT/$name" -- python3 "$R/bench.py" --no-cpu-baseline --steps 1 --warmup 0 "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"
+  timeout -s KILL 180 rocprofv3 --pmc $counters --output-format csv -d "$OUT/$name" -- python3 "$R/bench.py" --no-cpu-baseline --no-other-configs --steps 1 --warmup 0 "$@" > "$OUT/$name.json" 2> "$OUT/$name.err"
   rc=$?
   echo "pass $name rc=$rc"
   if [ $rc -ne 0 ]; then tail -5 "$OUT/$name.err"; exit $rc; fi

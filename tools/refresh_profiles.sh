@@ -13,7 +13,7 @@ RT_PROFILE_BLOCKS=1 timeout -k 10 120 python3 tools/perf_sweep.py inner_min 10 -
 step timeout -k 10 300 python3 tools/run_configs.py --only c1,c2,c5,c3,c4 --rooflines > "$OUT/stress_host.jsonl" 2> "$OUT/stress_host.err"
 step timeout -k 10 300 python3 tools/run_configs.py --only c5,c3,c4 --builder device > "$OUT/stress_device.jsonl" 2> "$OUT/stress_device.err"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err" || { tail -5 "$OUT/stats.err"; exit 1; }
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --no-cpu-baseline --no-other-configs > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err" || { tail -5 "$OUT/stats.err"; exit 1; }
 cd "$R"
 step bash tools/pmc_passes.sh "$OUT/pmc"
 python3 tools/pmc_summary.py "$OUT/pmc" render_kernel > "$OUT/pmc_summary.json"
