@@ -34,7 +34,7 @@ def _scene(G):
     return spheres, materials, rt.BVH(spheres, materials)
 
 
-def _check_against_fixture(name, G, world):
+def _check_against_fixture(name, G, world, bar=0.995):
     n = int(G["n_small"])
     got = world.trace_batch(G["org"], G["dir"])
     want = dict(prim=G["prim"], t=G["t"], normal=G["normal"], front=G["front"])
@@ -46,7 +46,7 @@ def _check_against_fixture(name, G, world):
     o_rays = int(G["render_stats"][0])
     print("%s: %d near-tie index differences on %d rays (rel dt %.1e); small render %.2f%% of pixels equal to 1e-9, rays %d vs oracle %d"
           % (name, ties, len(G["prim"]), rel_t, 100 * frac, st["rays"], o_rays))
-    assert frac >= 0.95
+    assert frac >= bar
     assert abs(st["rays"] - o_rays) <= 0.005 * o_rays
     return o_rays / float(int(G["small_width"]) * img.shape[0] * int(G["small_spp"])), G["rgb_sum"].mean() / int(G["small_spp"])
 
@@ -87,7 +87,9 @@ def test_stress_configuration_at_stated_size(name, spp, split):
     spheres, materials, world = _scene(G)
     info = world.info()
     assert info["n_spheres"] == int(G["n_small"]) + 1 and info["n_nodes_in_lds"] < info["n_device_nodes"]
-    o_path, o_mean = _check_against_fixture(name, G, world)
+    # (10^6 spheres spread over 1000 units: the last-bit differences of contracted multiply-adds are larger in absolute terms and more
+    # paths part ways -- observed 98.6 % there, 99.7 - 99.9 % on the other two)
+    o_path, o_mean = _check_against_fixture(name, G, world, bar=0.98 if name == "c4" else 0.995)
     path, mean = _full_frame_properties(name, G, world, spp, split)
     # the same scene through the same camera at 1/24 (1/48) of the resolution: path length and radiance agree statistically
     assert abs(path - o_path) <= 0.03 * o_path
@@ -116,5 +118,5 @@ def test_deep_bounce_configuration_live_against_oracle(oracle):
     want, ost = oworld.render(small.record().view(oracle.CONFIG_DTYPE), 9, 0, 6, nthreads=8)
     frac, worst = _pixel_agreement(got, want)
     print("c5 live render 128 x 72 x 6 at depth 200: %.2f%% of pixels equal to 1e-9, path length %.2f" % (100 * frac, st["rays"] / st["samples"]))
-    assert frac >= 0.95 and abs(st["rays"] - int(ost[0])) <= 0.005 * int(ost[0])
+    assert frac >= 0.995 and abs(st["rays"] - int(ost[0])) <= 0.005 * int(ost[0])  # (observed: 99.76 %)
     world.close()

@@ -102,7 +102,7 @@ def test_trace_primary_rays(world, oworld, oracle):
     want = oworld.trace_batch(org, d)
     ties, rel_t, dn = compare_hits(got, want)
     print("primary: %d rays, %d near-tie index differences, max rel dt %.2e, max dn %.2e" % (n, ties, rel_t, dn))
-    assert ties <= n // 1000
+    assert ties <= 4  # (none observed: exact-distance ties need two spheres hit at the same f64 distance)
     assert (want["prim"] >= 0).mean() > 0.5
 
 
@@ -278,8 +278,8 @@ def test_render_matches_oracle_small(world, oworld, oracle):
     want, ostats = oworld.render(cfg.record().view(oracle.CONFIG_DTYPE), 12345, 0, 8, nthreads=8)
     frac, worst = _pixel_agreement(got, want)
     print("render 96x54x8: %.2f%% pixels equal to 1e-9, worst |diff| %.3e, rays gpu %d oracle %d" % (100 * frac, worst, stats["rays"], ostats[0]))
-    # Paths are chaotic: a last-bit difference can send a deep path elsewhere, so a few pixels may differ by one sample.
-    assert frac >= 0.97
+    # Paths are chaotic: a last-bit difference can send a deep path elsewhere, so a few pixels may differ by one sample (observed: 99.98 %).
+    assert frac >= 0.995
     assert abs(stats["rays"] - int(ostats[0])) <= 0.002 * int(ostats[0])
     assert stats["samples"] == 96 * cam.image_height * 8
     q_got, q_want = rt.quantise(got, 8), oracle.quantise(want, 8)
@@ -416,7 +416,7 @@ def test_large_scene_uses_global_memory_and_matches_oracle(oracle):
     want, ostats = oworld.render(cfg.record().view(oracle.CONFIG_DTYPE), 5, 0, 4, nthreads=8)
     frac, worst = _pixel_agreement(got, want)
     print("20k spheres render 160x90x4: %.2f%% pixels equal to 1e-9, rays gpu %d oracle %d" % (100 * frac, stats["rays"], ostats[0]))
-    assert frac >= 0.97 and abs(stats["rays"] - int(ostats[0])) <= 0.002 * int(ostats[0])
+    assert frac >= 0.995 and abs(stats["rays"] - int(ostats[0])) <= 0.002 * int(ostats[0])  # (observed: 99.94 %)
     world.close()
 
 
@@ -429,7 +429,7 @@ def test_glass_metal_deep_bounce_scene(oracle):
     want, ostats = oworld.render(cfg.record().view(oracle.CONFIG_DTYPE), 11, 0, 4, nthreads=8)
     frac, worst = _pixel_agreement(got, want)
     print("glass/metal depth 200: %.2f%% pixels equal to 1e-9, mean path length %.2f" % (100 * frac, stats["rays"] / stats["samples"]))
-    assert frac >= 0.95
+    assert frac >= 0.995  # (observed: 99.94 %)
     assert abs(stats["rays"] - int(ostats[0])) <= 0.005 * int(ostats[0])
     world.close()
 
@@ -528,7 +528,8 @@ def test_device_built_tree_finds_the_same_hits(oracle, rtiow):
     got, stats = cfg.camera().render_sum(world, seed=5)
     want, ostats = oworld.render(cfg.record().view(oracle.CONFIG_DTYPE), 5, 0, 4, nthreads=8)
     frac, worst = _pixel_agreement(got, want)
-    assert frac >= 0.97 and abs(stats["rays"] - int(ostats[0])) <= 0.002 * int(ostats[0])
+    print("device-built tree render: %.2f%% of pixels equal to 1e-9" % (100 * frac))
+    assert frac >= 0.995 and abs(stats["rays"] - int(ostats[0])) <= 0.002 * int(ostats[0])
     with pytest.raises(rt.RtError):
         world.dump()  # there is no host tree
     world.close()

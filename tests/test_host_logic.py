@@ -141,6 +141,14 @@ def test_quantise_and_ppm_match_oracle(oracle):
         rt.write_ppm(1, rgb, w + 1, h, spp)
 
 
+def test_quantise_boundary_fixture_is_the_oracles_and_the_hosts(oracle):
+    # the committed byte-boundary vector (tests/golden/make_c1_fixture.py): the oracle still produces it, and so does the host quantiser
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quantise_boundaries.npz"))
+    sums, spp = z["sums"].reshape(-1, 3), int(z["spp"])
+    assert np.array_equal(oracle.quantise(sums, spp), z["bytes"])
+    assert np.array_equal(rt.quantise(sums, spp), z["bytes"])
+
+
 def test_rtiow_scene_follows_main_rs():
     spheres, materials = rt.scene_rtiow(1)
     assert len(spheres) == 488 and len(materials) == 488  # 4 fixed + 22 x 22 (src/main.rs:45-82)
