@@ -300,13 +300,6 @@ int rt_debug_set(const char* name, double value);
  * ancestors' boxes shrunk (a copy of `nodes` when nothing changes).  No counterpart in the reference. */
 int rt_debug_take_out_first_leaf(const void* nodes, size_t n_nodes, uint32_t root, void* nodes_out, uint32_t* first_leaf, uint32_t* walk_root);
 
-/* Measurement harness, not a product path (no rt_render* entry point calls it): the same samples of the whole
- * frame rendered by a wavefront pipeline -- one kernel per stage (generate, trace, shade, resolve) with ray queues
- * in device memory, rays that go on packed with wave ballots -- so that its profile can be laid next to the
- * persistent kernel's.  Same paths, hence the same frame up to the order of additions.  rgb_sum_dev is device
- * memory and is added to; runs on the default stream and waits for it. */
-int rt_experiment_wavefront_device(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
-                                   double* rgb_sum_dev, rt_render_stats* stats);
 
 /* `write_colour` (src/camera.rs:85-95) for n pixels: out is n x 3 bytes. Host only. */
 int rt_quantise(const double* rgb_sum, size_t n_pixels, uint64_t samples_per_pixel, uint8_t* out);

@@ -10,6 +10,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RAYTRACER_AMD_LIB names another build of the same library (used to compare kernel variants in one run).
 LIB_PATH = os.environ.get("RAYTRACER_AMD_LIB") or os.path.join(_HERE, "libraytracer_amd.so")
+# The product library plus the measurement harnesses (include/rt_experiments.h); tools that need them start with
+# RAYTRACER_AMD_LIB set to this path.
+EXPERIMENTS_LIB_PATH = os.path.join(_HERE, "libraytracer_amd_experiments.so")
 
 SPHERE_DTYPE = np.dtype([("center", "<f8", 3), ("radius", "<f8"), ("material", "<u4"), ("reserved", "<u4")])
 MATERIAL_DTYPE = np.dtype([("type", "<u4"), ("reserved", "<u4"), ("albedo", "<f8", 3), ("param", "<f8")])
@@ -96,7 +99,6 @@ EXPORTS = [
     "rt_render_multi",
     "rt_debug_set",
     "rt_debug_take_out_first_leaf",
-    "rt_experiment_wavefront_device",
     "rt_quantise",
     "rt_write_ppm",
     "rt_quantise_device",

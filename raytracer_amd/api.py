@@ -321,7 +321,10 @@ class Camera:
         return {k: stats[k][0].item() for k in RENDER_STATS_DTYPE.names} if want_stats else None
 
     def render_wavefront_device(self, bvh, rgb_sum_ptr, seed=0, spp_begin=0, spp_end=None):
-        """The measurement harness: the same samples through the wavefront pipeline (whole frame)."""
+        """The measurement harness: the same samples through the wavefront pipeline (whole frame).  Only
+        libraytracer_amd_experiments.so has it: start the process with RAYTRACER_AMD_LIB=raytracer_amd._lib.EXPERIMENTS_LIB_PATH."""
+        if not hasattr(_lib.lib(), "rt_experiment_wavefront_device"):
+            raise RuntimeError("the wavefront harness is not part of %s; set RAYTRACER_AMD_LIB=%s" % (_lib.LIB_PATH, _lib.EXPERIMENTS_LIB_PATH))
         if spp_end is None:
             spp_end = self.config.get("samples_per_pixel")
         stats = np.zeros(1, dtype=RENDER_STATS_DTYPE)

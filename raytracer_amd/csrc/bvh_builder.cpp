@@ -7,6 +7,7 @@
 #include <memory>
 #include <exception>
 #include <system_error>
+#include <cstdlib>
 #include <thread>
 
 namespace rta {
@@ -52,7 +53,12 @@ inline int choose_bucket(double min_t, double max_t, double t) {
 // Work below this many spheres stays on the calling thread.
 const size_t kParallelGrain = 16384;
 
+// Threads a build may use: the machine's, 16 at most; RT_HOST_THREADS in the environment sets another limit (1 .. 64).
 inline unsigned host_threads() {
+  if (const char* env = std::getenv("RT_HOST_THREADS")) {
+    const long v = std::strtol(env, nullptr, 10);
+    if (v >= 1 && v <= 64) return (unsigned)v;
+  }
   unsigned hw = std::thread::hardware_concurrency();
   return std::max(1u, std::min(hw ? hw : 1u, 16u));
 }

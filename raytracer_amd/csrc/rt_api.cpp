@@ -21,6 +21,9 @@
 
 #include "bvh_builder.h"
 #include "rt.h"
+#ifdef RTA_EXPERIMENTS
+#include "rt_experiments.h"
+#endif
 #include "rt_host.h"
 #include "rt_build.h"
 #include "rt_launch.h"
@@ -118,8 +121,10 @@ std::atomic<bool> g_force_staged_sum{false};
 std::atomic<uint32_t> g_wide_lds_stack{8};
 // Test hook: scenes created while this is set are walked through the four-wide tree even if they fit in LDS two-wide.
 std::atomic<bool> g_force_wide{false};
+#ifdef RTA_EXPERIMENTS
 // Paths the wavefront harness keeps in flight (whole samples of the frame, at least one).
 std::atomic<uint64_t> g_wavefront_paths{32u << 20};
+#endif
 
 // Partial sums of an allocating render call never exceed this; the sample range is cut into fewer chunks instead.
 constexpr uint64_t kWorkspaceLimit = 4ull << 30;
@@ -1408,6 +1413,7 @@ int rt_render_device_noalloc(const rt_scene* sc, const rt_config* cfg, uint64_t 
   });
 }
 
+#ifdef RTA_EXPERIMENTS  // built into libraytracer_amd_experiments.so only
 int rt_experiment_wavefront_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
                                    double* rgb_sum_dev, rt_render_stats* stats) {
   return guarded("rt_experiment_wavefront_device", [&]() -> int {
@@ -1459,6 +1465,7 @@ int rt_experiment_wavefront_device(const rt_scene* sc, const rt_config* cfg, uin
     return RT_OK;
   });
 }
+#endif
 
 int rt_render(const rt_scene* sc, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, const rt_rect* tile,
               double* rgb_sum, rt_render_stats* stats) {
@@ -1600,11 +1607,13 @@ int rt_debug_set(const char* name, double value) {
       g_force_global_stack.store(value != 0.0);
       return RT_OK;
     }
+#ifdef RTA_EXPERIMENTS
     if (key == "wavefront_paths") {
       if (!(value >= 1.0 && value <= 4e9)) return fail(RT_ERR_INVALID, "rt_debug_set: wavefront_paths must be in 1 .. 4e9");
       g_wavefront_paths.store((uint64_t)value);
       return RT_OK;
     }
+#endif
     if (key == "force_wide") {
       g_force_wide.store(value != 0.0);
       return RT_OK;

@@ -137,7 +137,7 @@ hipError_t static_scratch(int device, void** ptr, size_t* bytes);
 // out (bytes, 2-byte aligned) = write_colour of each of the n_components sums.
 hipError_t launch_quantise(const double* rgb_sum, size_t n_components, uint64_t spp, uint8_t* out, hipStream_t stream);
 
-// The wavefront pipeline kept for measurement (rt_wavefront.hip): samples [spp_begin, spp_end) of the whole frame added
+// The wavefront pipeline kept for measurement (rt_wavefront.hip, linked into libraytracer_amd_experiments.so only): samples [spp_begin, spp_end) of the whole frame added
 // into `frame`; workspace of wavefront_workspace_bytes(capacity) bytes, capacity a multiple of width x height.
 size_t wavefront_workspace_bytes(uint32_t capacity);
 hipError_t wavefront_render(const SceneDev& sc, const CameraDev& cam, uint64_t seed, uint32_t spp_begin, uint32_t spp_end, double* frame,

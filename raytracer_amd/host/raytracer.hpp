@@ -12,6 +12,7 @@
 // never throws).  Header-only; link with -lraytracer_amd.
 #pragma once
 
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <limits>
@@ -138,7 +139,11 @@ struct Sphere final : Hit {
 // src/bvh.rs:38-48: owns the primitives; the tree lives in the library.
 class BVH {
  public:
-  explicit BVH(std::vector<std::unique_ptr<Hit>> objects) : objects_(std::move(objects)) {
+  // Which GPUs hold a copy of the scene: the one that is current in the calling thread (what a process that was given
+  // one GPU of a node wants, and the default), or every GPU the process can see (one process driving the whole node;
+  // also chosen by RT_DEVICES=all in the environment).
+  enum class Devices { Current, All };
+  explicit BVH(std::vector<std::unique_ptr<Hit>> objects, Devices devices = Devices::Current) : objects_(std::move(objects)) {
     std::vector<rt_sphere> spheres;
     std::vector<rt_material> materials;
     std::unordered_map<const Material*, uint32_t> seen;  // an Arc shared by several spheres becomes one record
@@ -153,8 +158,16 @@ class BVH {
       }
       spheres.push_back({{s->center.x, s->center.y, s->center.z}, s->radius, it->second, 0});
     }
-    // one copy of the tree on every GPU of the node (null device list); Camera::render shares a frame out over them
-    check(rt_scene_create_multi(spheres.data(), spheres.size(), materials.data(), materials.size(), RT_BUILD_HOST_SAH, nullptr, 0, &scene_));
+    const char* env = std::getenv("RT_DEVICES");
+    if (devices == Devices::All || (env && std::string(env) == "all")) {
+      // one copy of the tree on every visible GPU (null device list); Camera::render shares a frame out over them
+      check(rt_scene_create_multi(spheres.data(), spheres.size(), materials.data(), materials.size(), RT_BUILD_HOST_SAH, nullptr, 0, &scene_));
+    } else {
+      int current = 0;
+      check(rt_device_get(&current));
+      const int32_t list[1] = {current};
+      check(rt_scene_create_multi(spheres.data(), spheres.size(), materials.data(), materials.size(), RT_BUILD_HOST_SAH, list, 1, &scene_));
+    }
   }
   ~BVH() {
     if (scene_) rt_scene_destroy(scene_);

@@ -71,6 +71,9 @@ pub struct rt_scene {
 
 extern "C" {
     pub fn rt_last_error() -> *const c_char;
+    pub fn rt_device_count(count: *mut c_int) -> c_int;
+    pub fn rt_device_set(ordinal: c_int) -> c_int;
+    pub fn rt_device_get(ordinal: *mut c_int) -> c_int;
     pub fn rt_scene_create(
         spheres: *const rt_sphere,
         n_spheres: usize,

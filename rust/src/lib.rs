@@ -63,7 +63,18 @@ unsafe impl Send for Scene {}
 unsafe impl Sync for Scene {}
 
 impl Scene {
+    /// A copy of the scene on the GPU that is current in the calling thread (`rt_device_set`): what a process that was
+    /// given one GPU of a node wants.
     pub fn new(spheres: &[GpuSphere]) -> Result<Self, Error> {
+        Self::create(spheres, false)
+    }
+
+    /// A copy on every GPU the process can see: one process driving the whole node (`render` then shares a frame out).
+    pub fn new_on_all_devices(spheres: &[GpuSphere]) -> Result<Self, Error> {
+        Self::create(spheres, true)
+    }
+
+    fn create(spheres: &[GpuSphere], all_devices: bool) -> Result<Self, Error> {
         let mut ids: Vec<usize> = Vec::new();
         let mut materials: Vec<ffi::rt_material> = Vec::new();
         let mut flat = Vec::with_capacity(spheres.len());
@@ -78,7 +89,10 @@ impl Scene {
             };
             flat.push(ffi::rt_sphere { center: s.center.to_array(), radius: s.radius, material: index as u32, reserved: 0 });
         }
-        // A copy of the scene on every GPU of the node (null device list): `render` and `render_ppm` use them all.
+        // A null device list means every visible GPU; else the current one alone.
+        let mut current: i32 = 0;
+        check(unsafe { ffi::rt_device_get(&mut current) })?;
+        let list = [current];
         let mut handle = ptr::null_mut();
         check(unsafe {
             ffi::rt_scene_create_multi(
@@ -87,8 +101,8 @@ impl Scene {
                 materials.as_ptr(),
                 materials.len(),
                 ffi::RT_BUILD_HOST_SAH,
-                ptr::null(),
-                0,
+                if all_devices { ptr::null() } else { list.as_ptr() },
+                if all_devices { 0 } else { 1 },
                 &mut handle,
             )
         })?;

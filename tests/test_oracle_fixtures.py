@@ -213,3 +213,42 @@ def test_direct_and_rejection_renders_agree_within_noise(oracle):
     cross = np.sqrt(((a - c) ** 2).mean())
     assert cross < 1.25 * noise
     assert abs(a.mean() - c.mean()) < 0.02 * a.mean()
+
+
+def test_camera_ray_draws_are_four_words_of_one_philox7_block(oracle):
+    # The rule the render loop draws camera rays by, restated here from the generator's known-answer-checked words alone:
+    # one Philox4x32-7 block with counter (pixel index, sample, 0, domain 0) and key = seed; uniform k = word k * 2^-32;
+    # (0, 1) the position in the pixel, (2, 3) the point on the lens by the direct map r = sqrt(u2), phi = 2 pi u3
+    # (src/camera.rs:114-136, src/vector.rs:29-40).  Pins the mapping so that oracle and kernels cannot drift together.
+    import raytracer_amd as rt  # (host code only: the configuration record)
+
+    cfg = rt.config_rtiow(830, 750, 50)
+    ocfg = cfg.record().view(oracle.CONFIG_DTYPE)
+    _, cam = oracle.camera_derive(ocfg)
+    seed = 0x1234567855AA33CC
+    rng = np.random.default_rng(17)
+    ijs = np.stack([rng.integers(0, 830, 64), rng.integers(0, 466, 64), rng.integers(0, 750, 64)], axis=1).astype(np.uint32)
+    org, d = oracle.primary_rays(ocfg, seed, ijs)
+    for (i, j, s), o_got, d_got in zip(ijs, org, d):
+        words = oracle.philox4x32([seed & 0xFFFFFFFF, seed >> 32], [int(j) * 830 + int(i), int(s), 0, 0], 7)
+        u = [int(w) / 4294967296.0 for w in words]
+        sample = cam["pixel00_loc"] + float(i) * cam["pixel_delta_u"] + float(j) * cam["pixel_delta_v"] \
+            + ((-0.5 + u[0]) * cam["pixel_delta_u"] + (-0.5 + u[1]) * cam["pixel_delta_v"])
+        r, phi = np.sqrt(u[2]), 2.0 * np.pi * u[3]
+        o = cam["center"] + r * np.cos(phi) * cam["defocus_disk_u"] + r * np.sin(phi) * cam["defocus_disk_v"]
+        want = (sample - o) / np.linalg.norm(sample - o)
+        assert np.abs(o_got - o).max() <= 1e-13 and np.abs(d_got - want).max() <= 1e-13
+    # a uniform is an exact multiple of 2^-32 below 1: the largest word gives 1 - 2^-32
+    assert 0xFFFFFFFF / 4294967296.0 == 1.0 - 2.0 ** -32
+
+
+def test_host_code_is_clean_under_the_sanitizers():
+    # bvh_builder.cpp (threaded build, flatten, four-wide collapse), rt_host.cpp (camera, quantiser, PPM text, scenes) and the
+    # oracle, compiled with -fsanitize=address,undefined and again with -fsanitize=thread, on scenes of 488 and 40 000 spheres
+    # (tools/sanitize/run.sh; the run with 10^6 spheres is recorded in profiles/)
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["bash", os.path.join(root, "tools", "sanitize", "run.sh"), "40000"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
+    assert p.stdout.count("all checks passed") == 2 and "exit status 0" in p.stdout

@@ -8,7 +8,7 @@ mkdir -p "$R/raytracer_amd/variants"
 cd "$R/raytracer_amd/csrc"
 HOST="-std=c++17 -O2 -fPIC -ffp-contract=off -I../../include -I. -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include"
 g++ $HOST "$@" -c bvh_builder.cpp -o /tmp/bvh_builder_$NAME.o
-g++ $HOST "$@" -c rt_api.cpp -o /tmp/rt_api_$NAME.o
+g++ $HOST -DRTA_EXPERIMENTS "$@" -c rt_api.cpp -o /tmp/rt_api_$NAME.o
 /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -I../../include -I. -Wall -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c rt_kernels.hip -o /tmp/rt_kernels_$NAME.o
 /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -I../../include -I. -Wall -fno-slp-vectorize "$@" -c rt_wavefront.hip -o /tmp/rt_wavefront_$NAME.o
 /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -I../../include -I. -Wall -fno-slp-vectorize "$@" -c rt_cuts.hip -o /tmp/rt_cuts_$NAME.o

@@ -9,7 +9,10 @@ import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the harness lives in the experiments library, not in the shipped one
+os.environ.setdefault("RAYTRACER_AMD_LIB", os.path.join(ROOT, "raytracer_amd", "libraytracer_amd_experiments.so"))
 
 
 def main():
