@@ -123,6 +123,12 @@ typedef struct rt_scene_info {
   uint64_t lds_bytes;       /* LDS each workgroup of the tree-walking kernels uses for this scene */
   uint32_t builder;         /* RT_BUILD_* that made the tree (the device builder falls back to the host for very deep trees) */
   uint32_t n_devices;       /* copies of the scene (1 unless made by rt_scene_create_multi); `device` is the first one's */
+  uint32_t peer_pairs;      /* ordered pairs (a, b) of copies on different GPUs ... */
+  uint32_t peer_pairs_enabled; /* ... and those of them where a's GPU can read b's memory (peer access over xGMI or PCIe, enabled at
+                               scene creation): equal to peer_pairs when a sample split is summed over the peer links, else through copies */
+  uint64_t peer_matrix;     /* bit a * 8 + b set: the GPU of copy a can read the memory of copy b's (copies 0 .. 7; the diagonal is set) */
+  uint32_t cut_entries;     /* longest entry list camera rays start from in this scene (rt_debug_set "tile_cuts") */
+  uint32_t reserved;
 } rt_scene_info;
 
 typedef struct rt_scene rt_scene;

@@ -60,6 +60,11 @@ SCENE_INFO_DTYPE = np.dtype(
         ("lds_bytes", "<u8"),
         ("builder", "<u4"),
         ("n_devices", "<u4"),
+        ("peer_pairs", "<u4"),
+        ("peer_pairs_enabled", "<u4"),
+        ("peer_matrix", "<u8"),
+        ("cut_entries", "<u4"),
+        ("reserved", "<u4"),
     ]
 )
 SHARD_DTYPE = np.dtype([("x0", "<u4"), ("y0", "<u4"), ("x1", "<u4"), ("y1", "<u4"), ("row_first", "<u4"), ("row_stride", "<u4"),

@@ -697,6 +697,14 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
   sc->info.build_ms = build_ms;
   sc->info.lds_bytes = tree_lds_bytes(r0.dev);
   sc->info.n_devices = (uint32_t)R;
+  for (size_t a = 0; a < R; ++a)
+    for (size_t b = 0; b < R; ++b) {
+      if (a < 8 && b < 8 && sc->peer[a][b]) sc->info.peer_matrix |= 1ull << (a * 8 + b);
+      if (sc->reps[a]->device == sc->reps[b]->device) continue;
+      ++sc->info.peer_pairs;
+      if (sc->peer[a][b]) ++sc->info.peer_pairs_enabled;
+    }
+  sc->info.cut_entries = r0.dev.cut_k;
 
   *out = sc.release();
   return RT_OK;

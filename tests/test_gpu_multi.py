@@ -60,6 +60,10 @@ def test_multi_scene_on_one_device_is_the_single_device_path(rtiow, single):
 
 def test_tile_partition_is_bit_identical(single, triple):
     assert triple.info()["n_devices"] == 3
+    # three copies on one GPU: no pair of different GPUs, and every copy can read every other's memory
+    ti = triple.info()
+    assert ti["peer_pairs"] == 0 and ti["peer_pairs_enabled"] == 0
+    assert all(ti["peer_matrix"] >> (a * 8 + b) & 1 for a in range(3) for b in range(3)) and ti["peer_matrix"] >> 27 == 0
     # 130 x 73: the last tile row and column stick out of the image; 200 samples are cut into several chunks
     cam = rt.config_rtiow(image_width=130, samples_per_pixel=200, max_depth=50).camera()
     want, st = cam.render_sum(single, seed=12345)

@@ -68,6 +68,7 @@ def test_scene_layout(world):
     # one 64-byte device node per split; this scene's tree, spheres, shading data and materials all sit in LDS
     assert info["n_device_nodes"] == 487 and info["n_nodes_in_lds"] == 487 and info["spheres_in_lds"] == 7
     assert info["lds_bytes"] <= 160 * 1024
+    assert info["cut_entries"] == 4 and info["peer_pairs"] == 0 and info["peer_matrix"] == 1
 
 
 def test_device_bvh_equals_oracle_bvh(world, oworld):
