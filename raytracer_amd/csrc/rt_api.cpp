@@ -126,6 +126,9 @@ std::atomic<bool> g_force_wide{false};
 std::atomic<uint64_t> g_wavefront_paths{32u << 20};
 #endif
 
+// RT_BUILD_AUTO: scenes of this many spheres or more are built on the device (host build 60 ms and up, device build 5 ms).
+constexpr size_t kAutoDeviceBuild = 65536;
+
 // Partial sums of an allocating render call never exceed this; the sample range is cut into fewer chunks instead.
 constexpr uint64_t kWorkspaceLimit = 4ull << 30;
 
@@ -347,9 +350,11 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
     rp.d_spheres = tree.d_spheres;
     rp.d_aux = tree.d_aux;
     RT_HIP(e);
-    if (tree.depth <= max_depth) {
+    // (a tree deeper than LDS has stack rows for is walked with its stacks in global memory, like a host tree; the builder itself numbers
+    // levels in eight bits)
+    if (tree.depth <= 250) {
       on_device = true;
-    } else {  // a tree too deep for the traversal stack: the caller falls back to the host builder
+    } else {  // the caller falls back to the host builder
       (void)hipFree(rp.d_nodes);
       (void)hipFree(rp.d_spheres);
       (void)hipFree(rp.d_aux);
@@ -516,7 +521,8 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
 int create_scene(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, uint32_t builder, const int32_t* devices,
                  size_t n_devices, bool current_device_only, rt_scene** out) {
   if (!out) return fail(RT_ERR_INVALID, "rt_scene_create: out is null");
-  if (builder > RT_BUILD_DEVICE_LBVH) return fail(RT_ERR_INVALID, "rt_scene_create: unknown builder");
+  if (builder > RT_BUILD_AUTO) return fail(RT_ERR_INVALID, "rt_scene_create: unknown builder");
+  if (builder == RT_BUILD_AUTO) builder = n >= kAutoDeviceBuild ? RT_BUILD_DEVICE_LBVH : RT_BUILD_HOST_SAH;
   *out = nullptr;
   if ((n && !spheres) || (nm && !materials)) return fail(RT_ERR_INVALID, "rt_scene_create: null array");
   if (n >= kMaxSlots) return fail(RT_ERR_LIMIT, "rt_scene_create: at most 16777199 spheres");
@@ -1143,7 +1149,7 @@ int rt_camera_derive(const rt_config* cfg, rt_camera* out) {
 }
 
 int rt_scene_create(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, rt_scene** out) {
-  return rt_scene_create_ex(spheres, n, materials, nm, RT_BUILD_HOST_SAH, out);
+  return rt_scene_create_ex(spheres, n, materials, nm, RT_BUILD_AUTO, out);
 }
 
 int rt_scene_create_ex(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, uint32_t builder, rt_scene** out) {

@@ -1,5 +1,5 @@
-// BVH construction on the device: a linear BVH (Morton order, the hierarchy of
-// Karras 2012 built in one pass, boxes fitted bottom-up), written straight into
+// BVH construction on the device: the spheres in Morton order, clustered bottom-up
+// (parallel locally-ordered clustering), boxes fitted bottom-up, written straight into
 // the layout the traversal kernels read.  It stands in for BVH::new
 // (src/bvh.rs:44-48) where building on the host would take longer than
 // rendering; the tree differs from the reference's binned-SAH tree, the closest
@@ -32,9 +32,10 @@ __device__ __forceinline__ float round_up(double v) {
 }
 
 // Sphere::aabb (src/sphere.rs:50-52) and the box's centroid (src/aabb.rs:23-25) per sphere;
-// per block, the bounds of the centroids.
+// per block, the bounds of the boxes (all spheres: `flags` null) or of the centroids of the spheres that are not flagged.
 __global__ __launch_bounds__(kThreads) void boxes_kernel(const rt_sphere* __restrict__ spheres, uint32_t n, Box6* __restrict__ prim_box,
-                                                          double* __restrict__ centroid, double* __restrict__ block_bounds) {
+                                                          double* __restrict__ centroid, const uint8_t* __restrict__ flags,
+                                                          double* __restrict__ block_bounds) {
   __shared__ double red[6][kThreads];
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   double c[3], lo[3], hi[3];
@@ -50,10 +51,15 @@ __global__ __launch_bounds__(kThreads) void boxes_kernel(const rt_sphere* __rest
       b.lo[a] = fmin(p0, p1);
       b.hi[a] = fmax(p0, p1);
       c[a] = b.lo[a] + 0.5 * (b.hi[a] - b.lo[a]);
-      centroid[3 * (size_t)i + a] = c[a];
-      lo[a] = hi[a] = c[a];
+      if (!flags) {
+        centroid[3 * (size_t)i + a] = c[a];
+        lo[a] = b.lo[a];
+        hi[a] = b.hi[a];
+      } else if (!flags[i]) {
+        lo[a] = hi[a] = c[a];
+      }
     }
-    prim_box[i] = b;
+    if (!flags) prim_box[i] = b;
   }
   for (int a = 0; a < 3; ++a) {
     red[a][threadIdx.x] = lo[a];
@@ -105,68 +111,132 @@ __device__ __forceinline__ uint64_t spread21(uint64_t v) {  // bit k of v moves 
   return v;
 }
 
-// 63-bit Morton code of each centroid inside the bounds of all centroids.
-__global__ __launch_bounds__(kThreads) void morton_kernel(const double* __restrict__ centroid, const double* __restrict__ bounds, uint32_t n,
-                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+// Spheres as large as the scene -- a radius above a quarter of the largest extent of all boxes: a ground sphere -- stand
+// apart: they take no part in the bounds the Morton codes are scaled by (so the codes keep their resolution for everything
+// else) and sort behind all others, which puts them in a subtree of their own directly under the root instead of somewhere
+// inside the Morton order, where such a sphere's box would blow up every ancestor's.
+__global__ __launch_bounds__(kThreads) void flag_kernel(const rt_sphere* __restrict__ spheres, uint32_t n, const double* __restrict__ box_bounds,
+                                                         uint8_t* __restrict__ flags) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
+  const double extent = fmax(box_bounds[3] - box_bounds[0], fmax(box_bounds[4] - box_bounds[1], box_bounds[5] - box_bounds[2]));
+  flags[i] = fabs(spheres[i].radius) > 0.25 * extent ? 1 : 0;
+}
+
+// 63-bit Morton code of each centroid inside the bounds of the centroids (those of the spheres that do not stand apart);
+// bit 63 for the spheres that do.
+__global__ __launch_bounds__(kThreads) void morton_kernel(const double* __restrict__ centroid, const double* __restrict__ bounds,
+                                                           const uint8_t* __restrict__ flags, uint32_t n, uint64_t* __restrict__ keys,
+                                                           uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  // One scale for the three axes (the largest extent): cells of the Morton grid are cubes, so a scene that is flat along one axis
+  // is not cut along that axis until the cells are as small as it is thick.  (Scaled per axis, the codes of a field of spheres on a
+  // large ground sphere were cut into height bands -- rings -- at every level: 20 % more node steps per ray.)
+  const double ext = fmax(bounds[3] - bounds[0], fmax(bounds[4] - bounds[1], bounds[5] - bounds[2]));
   uint64_t q[3];
   for (int a = 0; a < 3; ++a) {
-    const double lo = bounds[a], ext = bounds[3 + a] - lo;
-    double f = ext > 0.0 ? (centroid[3 * (size_t)i + a] - lo) / ext : 0.0;
+    double f = ext > 0.0 ? (centroid[3 * (size_t)i + a] - bounds[a]) / ext : 0.0;  // (no sphere inside the bounds: they are inverted, every code is 0)
     f = fmin(fmax(f * 2097152.0, 0.0), 2097151.0);
     q[a] = (uint64_t)f;
   }
-  keys[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+  keys[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2) | (flags[i] ? 1ull << 63 : 0ull);
   vals[i] = i;
 }
 
-// Length of the common prefix of the keys at sorted positions i and j; equal keys are told apart by position.
-__device__ __forceinline__ int prefix_len(const uint64_t* __restrict__ keys, int n, int i, int j) {
-  if (j < 0 || j >= n) return -1;
-  const uint64_t a = keys[i], b = keys[j];
-  if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
-  return __clzll((long long)(a ^ b));
+// ------------------------------------------------------------- clustering ----
+// The hierarchy: parallel locally-ordered clustering (Meister and Bittner 2018) over the Morton order.  The clusters --
+// at first the spheres in Morton order -- sit in an array; in every round each cluster looks kRadius places to either side
+// for the neighbour whose union with it has the least surface area, pairs that chose each other merge into a new node that
+// takes the place of the first of the two, and the array is packed.  The order of the array is kept, so the result is the
+// same in every run.  Rounds go on until one cluster is left: the root.  Against splitting at the highest differing bit of
+// the codes (Karras 2012) this builds what the surface-area heuristic wants from the bottom up: renders come within 4 - 8 % of
+// those through the host's binned-SAH tree (13 - 18 % before).  Only the topology is decided here, on f32 copies of the boxes;
+// the exact boxes are fitted afterwards (fit_kernel).  (Measured on fields of 10^4 .. 10^6 spheres: a radius of 3 or 4 gives the
+// best trees, 6 and 12 are 1 - 5 % slower to render, 25 and 50 up to 15 %: with a long reach small clusters pair up with
+// clusters of their own size far along the curve instead of growing compact.)
+#ifndef RTA_PLOC_RADIUS
+#define RTA_PLOC_RADIUS 4
+#endif
+constexpr int kRadius = RTA_PLOC_RADIUS;
+struct ClusterBox {
+  float lo[3], hi[3];
+};
+__device__ __forceinline__ float half_area_of_union(const ClusterBox& a, const ClusterBox& b) {
+  const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]), dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]),
+              dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+  return dx * dy + dy * dz + dz * dx;
 }
-
-// One thread per inner node i of the n - 1: its range of leaves and the split inside it.
-// Children: index of an inner node, or kLeafBit | sorted position of a leaf.
-__global__ __launch_bounds__(kThreads) void hierarchy_kernel(const uint64_t* __restrict__ keys, int n, uint32_t* __restrict__ left,
-                                                              uint32_t* __restrict__ right, uint32_t* __restrict__ parent_inner,
-                                                              uint32_t* __restrict__ parent_leaf) {
+__global__ __launch_bounds__(kThreads) void ploc_init_kernel(const Box6* __restrict__ prim_box, const uint32_t* __restrict__ vals, uint32_t n,
+                                                              uint32_t* __restrict__ ref, ClusterBox* __restrict__ box) {
+  const uint32_t k = blockIdx.x * kThreads + threadIdx.x;
+  if (k >= n) return;
+  const Box6 b = prim_box[vals[k]];
+  ClusterBox c;
+  for (int a = 0; a < 3; ++a) c.lo[a] = (float)b.lo[a], c.hi[a] = (float)b.hi[a];
+  ref[k] = kLeafBit | k;
+  box[k] = c;
+}
+// nearest[i]: the neighbour within kRadius places whose union with cluster i has the least area (of equals the closer, then the earlier one)
+__global__ __launch_bounds__(kThreads) void ploc_nearest_kernel(const ClusterBox* __restrict__ box, int m, uint32_t* __restrict__ nearest) {
   const int i = blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n - 1) return;
-  const int d = prefix_len(keys, n, i, i + 1) > prefix_len(keys, n, i, i - 1) ? 1 : -1;
-  const int dmin = prefix_len(keys, n, i, i - d);
-  int lmax = 2;
-  while (prefix_len(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
-  int l = 0;
-  for (int t = lmax / 2; t >= 1; t /= 2)
-    if (prefix_len(keys, n, i, i + (l + t) * d) > dmin) l += t;
-  const int j = i + l * d;
-  const int dnode = prefix_len(keys, n, i, j);
-  int s = 0, t = l;
-  do {
-    t = (t + 1) / 2;
-    if (prefix_len(keys, n, i, i + (s + t) * d) > dnode) s += t;
-  } while (t > 1);
-  const int gamma = i + s * d + min(d, 0);
-  const int lo = min(i, j), hi = max(i, j);
-  if (lo == gamma) {
-    left[i] = kLeafBit | (uint32_t)gamma;
-    parent_leaf[gamma] = (uint32_t)i;
-  } else {
-    left[i] = (uint32_t)gamma;
-    parent_inner[gamma] = (uint32_t)i;
+  if (i >= m) return;
+  const ClusterBox mine = box[i];
+  float best = __builtin_inff();
+  int best_j = i > 0 ? i - 1 : 1;  // (what stays if no area compares below infinity)
+  for (int d = 1; d <= kRadius; ++d) {
+    for (int s = -1; s <= 1; s += 2) {
+      const int j = i + s * d;
+      if (j < 0 || j >= m) continue;
+      const float a = half_area_of_union(mine, box[j]);
+      if (a < best) {
+        best = a;
+        best_j = j;
+      }
+    }
   }
-  if (hi == gamma + 1) {
-    right[i] = kLeafBit | (uint32_t)(gamma + 1);
-    parent_leaf[gamma + 1] = (uint32_t)i;
+  nearest[i] = (uint32_t)best_j;  // (m >= 2: there is a neighbour)
+}
+// marks[i]: low word 1 if cluster i stays in the array (it is not the second of a merging pair), high word 1 if it is the first of one
+__global__ __launch_bounds__(kThreads) void ploc_mark_kernel(const uint32_t* __restrict__ nearest, int m, unsigned long long* __restrict__ marks) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= m) return;
+  const int j = (int)nearest[i];
+  const bool mutual = (int)nearest[j] == i;
+  marks[i] = (mutual && j < i ? 0ull : 1ull) | (mutual && i < j ? 1ull << 32 : 0ull);
+}
+// `scan` = exclusive prefix sums of marks.  Writes the packed array and the new nodes (ids from next_id on, in array order).
+__global__ __launch_bounds__(kThreads) void ploc_merge_kernel(const uint32_t* __restrict__ ref, const ClusterBox* __restrict__ box,
+                                                               const uint32_t* __restrict__ nearest, const unsigned long long* __restrict__ marks,
+                                                               const unsigned long long* __restrict__ scan, int m, uint32_t next_id,
+                                                               uint32_t* __restrict__ ref_out, ClusterBox* __restrict__ box_out,
+                                                               uint32_t* __restrict__ left, uint32_t* __restrict__ right,
+                                                               uint32_t* __restrict__ parent_inner, uint32_t* __restrict__ parent_leaf,
+                                                               unsigned long long* __restrict__ totals) {
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= m) return;
+  const unsigned long long mark = marks[i], before = scan[i];
+  if (i == m - 1) *totals = before + mark;  // clusters left (low word) and nodes made (high word) after this round
+  if (!(mark & 1ull)) return;
+  const uint32_t pos = (uint32_t)before;
+  if (mark >> 32) {
+    const int j = (int)nearest[i];
+    const uint32_t id = next_id + (uint32_t)(before >> 32);
+    const uint32_t a = ref[i], b = ref[j];
+    left[id] = a;
+    right[id] = b;
+    if (a & kLeafBit) parent_leaf[a & ~kLeafBit] = id; else parent_inner[a] = id;
+    if (b & kLeafBit) parent_leaf[b & ~kLeafBit] = id; else parent_inner[b] = id;
+    parent_inner[id] = 0xffffffffu;  // until a later round gives it a parent: the last node made is the root
+    const ClusterBox x = box[i], y = box[j];
+    ClusterBox u;
+    for (int k = 0; k < 3; ++k) u.lo[k] = fminf(x.lo[k], y.lo[k]), u.hi[k] = fmaxf(x.hi[k], y.hi[k]);
+    ref_out[pos] = id;
+    box_out[pos] = u;
   } else {
-    right[i] = (uint32_t)(gamma + 1);
-    parent_inner[gamma + 1] = (uint32_t)i;
+    ref_out[pos] = ref[i];
+    box_out[pos] = box[i];
   }
-  if (i == 0) parent_inner[0] = 0xffffffffu;
 }
 
 __device__ __forceinline__ Box6 child_box(uint32_t ref, const Box6* __restrict__ prim_box, const uint32_t* __restrict__ vals,
@@ -229,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void rank_kernel(int n_inner, const uint3
 __global__ __launch_bounds__(kThreads) void emit_nodes_kernel(int n_inner, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
                                                                const uint32_t* __restrict__ new_of, const Box6* __restrict__ prim_box,
                                                                const uint32_t* __restrict__ vals, const Box6* __restrict__ node_box,
-                                                               float4* __restrict__ nodes, float* __restrict__ bound) {
+                                                               float4* __restrict__ nodes, float* __restrict__ bound, uint32_t root) {
   const int i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n_inner) return;
   uint32_t r0 = left[i], r1 = right[i];
@@ -263,8 +333,8 @@ __global__ __launch_bounds__(kThreads) void emit_nodes_kernel(int n_inner, const
   dst[1] = q1;
   dst[2] = q2;
   dst[3] = q3;
-  if (i == 0) {  // the root's box bounds every plane of the tree
-    const Box6 rb = node_box[0];
+  if ((uint32_t)i == root) {  // the root's box bounds every plane of the tree
+    const Box6 rb = node_box[root];
     double m = 0.0;
     for (int a = 0; a < 3; ++a) m = fmax(m, fmax(fabs(rb.lo[a]), fabs(rb.hi[a])));
     *bound = round_up(m);
@@ -442,7 +512,7 @@ hipError_t device_build_lbvh(const rt_sphere* h_spheres, size_t n_, const uint8_
   const unsigned blocks = (n + kThreads - 1) / kThreads, blocks_inner = (n_inner + kThreads - 1) / kThreads;
 
   Scratch d_in, d_mtype, prim_box, centroid, block_bounds, bounds, keys, keys2, vals, vals2, left, right, parent_inner, parent_leaf, node_box,
-      arrivals, level, level2, ids, order, new_of, misc, sort_tmp;
+      arrivals, level, level2, ids, order, new_of, misc, sort_tmp, flags;
   RTB(d_in.alloc((size_t)n * sizeof(rt_sphere)));
   RTB(d_mtype.alloc(n_materials));
   RTB(hipMemcpyAsync(d_in.p, h_spheres, (size_t)n * sizeof(rt_sphere), hipMemcpyHostToDevice, stream));
@@ -451,6 +521,7 @@ hipError_t device_build_lbvh(const rt_sphere* h_spheres, size_t n_, const uint8_
   RTB(centroid.alloc((size_t)n * 24));
   RTB(block_bounds.alloc((size_t)blocks * 48));
   RTB(bounds.alloc(48));
+  RTB(flags.alloc(n));
   RTB(keys.alloc((size_t)n * 8));
   RTB(keys2.alloc((size_t)n * 8));
   RTB(vals.alloc((size_t)n * 4));
@@ -470,24 +541,70 @@ hipError_t device_build_lbvh(const rt_sphere* h_spheres, size_t n_, const uint8_
   RTB(hipMemsetAsync(arrivals.p, 0, (size_t)n_inner * 4, stream));
   RTB(hipMemsetAsync(misc.p, 0, 16, stream));
 
+  // boxes and their bounds; which spheres stand apart; the centroid bounds of the others; Morton codes
   hipLaunchKernelGGL(boxes_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, prim_box.as<Box6>(), centroid.as<double>(),
-                     block_bounds.as<double>());
+                     (const uint8_t*)nullptr, block_bounds.as<double>());
   hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(kThreads), 0, stream, block_bounds.as<double>(), blocks, bounds.as<double>());
-  hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(kThreads), 0, stream, centroid.as<double>(), bounds.as<double>(), n, keys.as<uint64_t>(),
-                     vals.as<uint32_t>());
+  hipLaunchKernelGGL(flag_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, bounds.as<double>(), flags.as<uint8_t>());
+  hipLaunchKernelGGL(boxes_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, prim_box.as<Box6>(), centroid.as<double>(),
+                     flags.as<uint8_t>(), block_bounds.as<double>());
+  hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(kThreads), 0, stream, block_bounds.as<double>(), blocks, bounds.as<double>());
+  hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(kThreads), 0, stream, centroid.as<double>(), bounds.as<double>(), flags.as<uint8_t>(), n,
+                     keys.as<uint64_t>(), vals.as<uint32_t>());
   RTB(hipGetLastError());
 
   size_t tmp_bytes = 0, tmp_bytes2 = 0;
-  RTB(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), n, 0, 63,
+  RTB(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), n, 0, 64,
                                 stream));
   RTB(rocprim::radix_sort_pairs(nullptr, tmp_bytes2, level.as<uint32_t>(), level2.as<uint32_t>(), ids.as<uint32_t>(), order.as<uint32_t>(), n_inner,
                                 0, 8, stream));
   RTB(sort_tmp.alloc(tmp_bytes > tmp_bytes2 ? tmp_bytes : tmp_bytes2));
-  RTB(rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), n, 0, 63,
+  RTB(rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), n, 0, 64,
                                 stream));
 
-  hipLaunchKernelGGL(hierarchy_kernel, dim3(blocks_inner), dim3(kThreads), 0, stream, keys2.as<uint64_t>(), (int)n, left.as<uint32_t>(),
-                     right.as<uint32_t>(), parent_inner.as<uint32_t>(), parent_leaf.as<uint32_t>());
+  // clustering rounds over the Morton order (ping-pong arrays; the host reads the two counts back after every round)
+  Scratch ref_a, ref_b, box_a, box_b, nearest, marks, scan, totals;
+  RTB(ref_a.alloc((size_t)n * 4));
+  RTB(ref_b.alloc((size_t)n * 4));
+  RTB(box_a.alloc((size_t)n * sizeof(ClusterBox)));
+  RTB(box_b.alloc((size_t)n * sizeof(ClusterBox)));
+  RTB(nearest.alloc((size_t)n * 4));
+  RTB(marks.alloc((size_t)n * 8));
+  RTB(scan.alloc((size_t)n * 8));
+  RTB(totals.alloc(8));
+  size_t scan_bytes = 0;
+  RTB(rocprim::exclusive_scan(nullptr, scan_bytes, marks.as<unsigned long long>(), scan.as<unsigned long long>(), 0ull, n,
+                              rocprim::plus<unsigned long long>(), stream));
+  Scratch scan_tmp;
+  RTB(scan_tmp.alloc(scan_bytes));
+  hipLaunchKernelGGL(ploc_init_kernel, dim3(blocks), dim3(kThreads), 0, stream, prim_box.as<Box6>(), vals2.as<uint32_t>(), n, ref_a.as<uint32_t>(),
+                     box_a.as<ClusterBox>());
+  uint32_t m = n, next_id = 0, root_id = 0;
+  Scratch *ref_in = &ref_a, *ref_out = &ref_b, *box_in = &box_a, *box_out = &box_b;
+  while (m > 1) {
+    const unsigned bm = (m + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(ploc_nearest_kernel, dim3(bm), dim3(kThreads), 0, stream, box_in->as<ClusterBox>(), (int)m, nearest.as<uint32_t>());
+    hipLaunchKernelGGL(ploc_mark_kernel, dim3(bm), dim3(kThreads), 0, stream, nearest.as<uint32_t>(), (int)m, marks.as<unsigned long long>());
+    size_t bytes = scan_bytes;
+    RTB(rocprim::exclusive_scan(scan_tmp.p, bytes, marks.as<unsigned long long>(), scan.as<unsigned long long>(), 0ull, m,
+                                rocprim::plus<unsigned long long>(), stream));
+    hipLaunchKernelGGL(ploc_merge_kernel, dim3(bm), dim3(kThreads), 0, stream, ref_in->as<uint32_t>(), box_in->as<ClusterBox>(),
+                       nearest.as<uint32_t>(), marks.as<unsigned long long>(), scan.as<unsigned long long>(), (int)m, next_id,
+                       ref_out->as<uint32_t>(), box_out->as<ClusterBox>(), left.as<uint32_t>(), right.as<uint32_t>(), parent_inner.as<uint32_t>(),
+                       parent_leaf.as<uint32_t>(), totals.as<unsigned long long>());
+    RTB(hipGetLastError());
+    unsigned long long t = 0;
+    RTB(hipMemcpyAsync(&t, totals.p, 8, hipMemcpyDeviceToHost, stream));
+    RTB(hipStreamSynchronize(stream));
+    const uint32_t left_over = (uint32_t)t, made = (uint32_t)(t >> 32);
+    if (made == 0 || left_over + made != m) return hipErrorUnknown;  // (every round merges at least the closest pair)
+    next_id += made;
+    m = left_over;
+    std::swap(ref_in, ref_out);
+    std::swap(box_in, box_out);
+  }
+  if (next_id != n_inner) return hipErrorUnknown;
+  root_id = n_inner - 1;  // the last node made
   hipLaunchKernelGGL(fit_kernel, dim3(blocks), dim3(kThreads), 0, stream, (int)n, left.as<uint32_t>(), right.as<uint32_t>(),
                      parent_inner.as<uint32_t>(), parent_leaf.as<uint32_t>(), prim_box.as<Box6>(), vals2.as<uint32_t>(), node_box.as<Box6>(),
                      arrivals.as<uint32_t>());
@@ -504,7 +621,7 @@ hipError_t device_build_lbvh(const rt_sphere* h_spheres, size_t n_, const uint8_
   RTB(hipMalloc(&out->d_aux, (size_t)n * 16));
   hipLaunchKernelGGL(emit_nodes_kernel, dim3(blocks_inner), dim3(kThreads), 0, stream, (int)n_inner, left.as<uint32_t>(), right.as<uint32_t>(),
                      new_of.as<uint32_t>(), prim_box.as<Box6>(), vals2.as<uint32_t>(), node_box.as<Box6>(), static_cast<float4*>(out->d_nodes),
-                     misc.as<float>() + 1);
+                     misc.as<float>() + 1, root_id);
   hipLaunchKernelGGL(emit_spheres_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), vals2.as<uint32_t>(), n,
                      d_mtype.as<uint8_t>(), static_cast<double*>(out->d_spheres), static_cast<double2*>(out->d_aux));
   RTB(hipGetLastError());

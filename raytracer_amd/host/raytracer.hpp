@@ -161,12 +161,12 @@ class BVH {
     const char* env = std::getenv("RT_DEVICES");
     if (devices == Devices::All || (env && std::string(env) == "all")) {
       // one copy of the tree on every visible GPU (null device list); Camera::render shares a frame out over them
-      check(rt_scene_create_multi(spheres.data(), spheres.size(), materials.data(), materials.size(), RT_BUILD_HOST_SAH, nullptr, 0, &scene_));
+      check(rt_scene_create_multi(spheres.data(), spheres.size(), materials.data(), materials.size(), RT_BUILD_AUTO, nullptr, 0, &scene_));
     } else {
       int current = 0;
       check(rt_device_get(&current));
       const int32_t list[1] = {current};
-      check(rt_scene_create_multi(spheres.data(), spheres.size(), materials.data(), materials.size(), RT_BUILD_HOST_SAH, list, 1, &scene_));
+      check(rt_scene_create_multi(spheres.data(), spheres.size(), materials.data(), materials.size(), RT_BUILD_AUTO, list, 1, &scene_));
     }
   }
   ~BVH() {

@@ -100,7 +100,7 @@ impl Scene {
                 flat.len(),
                 materials.as_ptr(),
                 materials.len(),
-                ffi::RT_BUILD_HOST_SAH,
+                ffi::RT_BUILD_AUTO,
                 if all_devices { ptr::null() } else { list.as_ptr() },
                 if all_devices { 0 } else { 1 },
                 &mut handle,

@@ -776,3 +776,20 @@ def test_material_table_shares_equal_materials(oracle, rtiow):
     assert np.array_equal(il, io)
     for w in (a, b, lone, one):
         w.close()
+
+
+def test_auto_builder_takes_the_device_from_65536_spheres_on():
+    small = rt.BVH(*rt.scene_field(2, 3000, 0.3, 0.3), builder=rt.BUILD_AUTO)
+    assert small.info()["builder"] == rt.BUILD_HOST_SAH
+    small.close()
+    spheres, materials = rt.scene_field(2, 70000, 0.3, 0.3)
+    big = rt.BVH(spheres, materials, builder=rt.BUILD_AUTO)
+    host = rt.BVH(spheres, materials, builder=rt.BUILD_HOST_SAH)
+    assert big.info()["builder"] == rt.BUILD_DEVICE_LBVH and big.info()["build_ms"] < host.info()["build_ms"]
+    cam = rt.config_field(70000, 128, 4, 30).camera()
+    a, sa = cam.render_sum(big, seed=3)
+    b, sb = cam.render_sum(host, seed=3)
+    same = np.abs(a - b).max(axis=2) <= 1e-9 * np.maximum(1.0, np.abs(b).max(axis=2))  # two trees: the same hits up to exact ties
+    assert same.mean() >= 0.995 and abs(sa["rays"] - sb["rays"]) <= 0.002 * sb["rays"]
+    big.close()
+    host.close()
