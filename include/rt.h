@@ -282,7 +282,7 @@ int rt_render_device_noalloc(const rt_scene* scene, const rt_config* cfg, uint64
 
 /* Tuning knobs and test hooks; not part of the stable interface.  Known names:
  * "inner_min" (lanes of 64 that must want the inner-node block for a wave to run
- * it without counting the other blocks; until it is set: 10 for scenes walked in LDS, 6 for larger ones), "leaf_min" (lanes waiting at leaves that make the leaf block run between
+ * it without counting the other blocks; until it is set: 10 for scenes walked in LDS, 8 for larger ones), "leaf_min" (lanes waiting at leaves that make the leaf block run between
  * inner-node rounds; 8), "both_min" (when the inner-node or the leaf
  * block is due, the other of the two runs as well if this many lanes want it), "chunk_spp", "target_units" and "batches_per_wave" (how a
  * call's sample range is cut into units of work), "quad_tiles" (1, the default: the 64 lanes of a wave start on a 4x4 block of

@@ -98,7 +98,7 @@ struct DeviceGuard {  // makes a device current for the duration of a call
 
 // Tunables (rt_debug_set).  Atomics: a render call reads each of them once, when it starts.
 // Lanes (of 64) that must want the inner-node block for a wave to run it without looking at the other blocks.
-std::atomic<uint32_t> g_inner_min{0};  // 0 (only as the initial value): 10 for the two-wide walk, 6 for the four-wide one
+std::atomic<uint32_t> g_inner_min{0};  // 0 (only as the initial value): 10 for the two-wide walk, 8 for the four-wide one
 // Lanes that must want the other traversal block (inner or leaf) for it to run in the same round as the one that is due.
 std::atomic<uint32_t> g_both_min{8};
 // Lanes waiting at leaves that make the leaf block run between inner-node rounds.
@@ -861,7 +861,7 @@ int plan_render(const Replica& rp, const CameraDev& cam, uint64_t seed, const rt
     P.time_scale = std::ldexp(1.0f, -(e + 5));
   }
   P.inner_min = g_inner_min.load();
-  if (P.inner_min == 0) P.inner_min = P.sc.wide ? 6u : 10u;  // the four-wide walk waits on its loads: it gains from running with fewer lanes
+  if (P.inner_min == 0) P.inner_min = P.sc.wide ? 8u : 10u;  // the four-wide walk waits on its loads: it gains from running with fewer lanes
   P.both_min = g_both_min.load();
   P.leaf_min = g_leaf_min.load();
   if (P.sc.wide) {  // the stack entries beyond those kept in LDS
