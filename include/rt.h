@@ -275,8 +275,9 @@ int rt_render_multi(const rt_scene* scene, const rt_config* cfg, uint64_t seed, 
  * refused with RT_ERR_LIMIT; entry lists that no longer fit are left out (same frame, rendered more slowly).  The
  * kernels are enqueued on `stream`; with stats == NULL the call returns without waiting for them, otherwise it
  * waits and fills stats (kernel_ms stays 0: no events).  All calls on one GPU share that GPU's array: calls that
- * overlap in time on one GPU race (two calls without stats on different streams already do), and nothing detects
- * it -- serialise them on one stream or wait in between. */
+ * overlap in time on one GPU race (two calls without stats on different streams already do).  Two host threads
+ * inside the call at once on one GPU are refused (RT_ERR_INVALID); kernels still running after a call returned are
+ * not detected -- serialise such calls on one stream or wait in between. */
 int rt_render_device_noalloc(const rt_scene* scene, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
                              const rt_rect* tile, double* rgb_sum_dev, void* stream, rt_render_stats* stats);
 

@@ -1370,6 +1370,18 @@ int rt_render_device(const rt_scene* sc, const rt_config* cfg, uint64_t seed, ui
   return rt_render_shard_device(sc, cfg, seed, &sh, rgb_sum_dev, stream, stats);
 }
 
+namespace {
+// One host thread at a time enqueues work on a GPU's static workspace.  (This keeps two callers from interleaving their memsets and
+// launches; it cannot see a call whose kernels are still running on another stream after it returned: that remains the caller's to avoid.)
+std::atomic_flag g_static_busy[64] = {};
+struct StaticBusy {
+  std::atomic_flag* f = nullptr;
+  ~StaticBusy() {
+    if (f) f->clear(std::memory_order_release);
+  }
+};
+}  // namespace
+
 int rt_render_device_noalloc(const rt_scene* sc, const rt_config* cfg, uint64_t seed, uint32_t spp_begin, uint32_t spp_end,
                              const rt_rect* tile, double* rgb_sum_dev, void* stream, rt_render_stats* stats) {
   return guarded("rt_render_device_noalloc", [&]() -> int {
@@ -1385,6 +1397,12 @@ int rt_render_device_noalloc(const rt_scene* sc, const rt_config* cfg, uint64_t 
     Replica& rp = *sc->reps[0];
     DeviceGuard g(rp.device);
     RT_HIP(g.status);
+    StaticBusy busy;
+    if (rp.device >= 0 && rp.device < 64) {
+      if (g_static_busy[rp.device].test_and_set(std::memory_order_acquire))
+        return fail(RT_ERR_INVALID, "rt_render_device_noalloc: another call is enqueueing on this GPU's static workspace; calls on one GPU must not overlap");
+      busy.f = &g_static_busy[rp.device];
+    }
     Workspace ws;
     rc = static_workspace(rp.device, &ws);
     if (rc) return rc;
