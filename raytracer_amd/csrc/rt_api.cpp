@@ -512,6 +512,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   dev.single_leaves = single ? 1u : 0u;
   dev.first_leaf = wide && !wide_peel ? kRefNone : first_leaf;
   if (!wide && first_leaf != kRefNone) dev.root = walk_root;
+  if (n > 0) RT_HIP(preload_render(dev));
   *on_device_out = on_device;
   *depth_out = tree_depth;
   *n_dev_nodes_out = n_final_nodes;

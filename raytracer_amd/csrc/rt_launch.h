@@ -127,6 +127,8 @@ hipError_t launch_primary_rays(const CameraDev& cam, uint64_t seed, const uint32
                                hipStream_t stream);
 // profile: run the variant that also fills the profiling counters.
 hipError_t launch_render(const RenderParams& P, int blocks, bool profile, hipStream_t stream);
+// Loads the code of the scene's render kernel ahead of the first render (scene creation calls it).
+hipError_t preload_render(const SceneDev& sc);
 hipError_t launch_reduce_chunks(const double* partial, double* out, uint32_t n_chunks, uint32_t x0, uint32_t y0, uint32_t y1, uint32_t tile_w,
                                 uint32_t local_rows, uint32_t row_first, uint32_t row_stride, uint32_t width, hipStream_t stream);
 // out[k] += src[0][k] + ... + src[n_src-1][k] (in that order) for k in [begin, end); at most kMaxAddFrames sources.
