@@ -135,3 +135,25 @@ def test_tiny_scenes():
             _check(_both_ways(world, cfg.camera(), seed=1))
         finally:
             world.close()
+
+
+def test_entry_lists_save_node_steps(capfd):
+    # the lists must not only be harmless but in use: the instrumented kernel counts node steps
+    import os
+
+    spheres, materials = rt.scene_rtiow(1)
+    cam = rt.config_rtiow(image_width=320, samples_per_pixel=8, max_depth=50).camera()
+    world = rt.BVH(spheres, materials)
+    os.environ["RT_PROFILE_BLOCKS"] = "1"
+    try:
+        steps = {}
+        for k in (0.0, 8.0):
+            _set(b"tile_cuts", k)
+            _, st = cam.render_sum(world, seed=3)
+            steps[k] = st["node_steps"] / st["rays"]
+    finally:
+        del os.environ["RT_PROFILE_BLOCKS"]
+        _set(b"tile_cuts", 8.0)
+        world.close()
+    capfd.readouterr()  # (the instrumented kernel prints its block profile)
+    assert steps[0.0] > 8.0 and steps[8.0] < 0.8 * steps[0.0], steps
