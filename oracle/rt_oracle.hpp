@@ -9,17 +9,21 @@
 // Parity status: the slab test, the AABB algebra and Sphere::aabb /
 // clipped_aabb are pinned by the reference's own unit tests
 // (src/aabb.rs:89-194, src/sphere.rs:83-117).  The camera, get_ray, the sky
-// branch and the recursion of ray_colour, Sphere::hit (on the ground sphere),
-// HitRecord::new, the Lambertian scatter, the Metal scatter without fuzz (with
-// vector::reflect) and write_colour are pinned by the example render the
-// reference keeps in its repository (image.png): the sky and the sky mirrored
-// in the large metal sphere byte for byte, the far ground by its mean colour
-// (tests/test_reference_image.py).  BVH::new, BVH::hit, the fuzz of the metal
-// scatter, the dielectric scatter and the lens sampler have no test, fixture or
-// output in the reference that reaches them, and the reference cannot be built
-// here (no Rust toolchain), so for those parity is UNPINNED: the restatement is
-// reviewable line against line and is exercised by analytic known-answer
-// tests only.
+// branch and the recursion of ray_colour, Sphere::hit (on the ground sphere and
+// on the unit spheres), HitRecord::new with its front-face rule, the Lambertian
+// scatter, the Metal scatter without fuzz (with vector::reflect), the refracting
+// branch of the Dielectric scatter (with vector::refract), the lens sampler and
+// write_colour are pinned by the example render the reference keeps in its
+// repository (image.png): the sky and the sky mirrored in the large metal sphere
+// byte for byte; the far ground and the sky seen through the large glass sphere
+// by their mean colours (the latter tells an index of refraction of 1.5 from 1.45);
+// the lens by the profile of the smeared horizon (tests/test_reference_image.py).
+// BVH::new and BVH::hit beyond the four fixed spheres, the fuzz of the metal
+// scatter and Schlick's reflectance (which weighs a few per cent in the glass
+// region) have no test, fixture or output in the reference that reaches them,
+// and the reference cannot be built here (no Rust toolchain), so for those
+// parity is UNPINNED: the restatement is reviewable line against line and is
+// exercised by analytic known-answer tests only.
 //
 // Arithmetic rules taken from the reference's dependencies (glam 0.24.2,
 // rand 0.8.5; versions from Cargo.lock): DVec3 is three scalar f64; dot is

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/reference_image_rows.npz: the top 150 rows (RGB, 8 bits) of the example render the reference
+"""Writes tests/golden/reference_image_rows.npz: the top 224 rows (RGB, 8 bits) of the example render the reference
 keeps in its repository (image.png, 830 x 466, shown in its README.md:4), the only output of the reference itself
 that exists.  Its scene was random (src/main.rs:57-82 draws from an unseeded generator), but two regions of the
 image do not depend on the random spheres: the sky above the horizon, which is a function of the camera, the sky
 gradient and write_colour alone (src/camera.rs:40-82, 85-95, 103-107, 114-136), and the ground far outside the
 field of small spheres, whose mean colour is a function of the ground's sphere test, the hit record, the Lambertian
 scatter and the recursion of ray_colour (src/sphere.rs:29-48, src/hit.rs:18-31, src/material.rs:21-30,
-src/camera.rs:98-112).  tests/test_reference_image.py compares the oracle and the GPU path with these rows.
+src/camera.rs:98-112).  Two more follow from the three fixed spheres (src/main.rs:49-55): the part of the large metal
+sphere that mirrors only sky, and the part of the large glass sphere through which only sky is seen (rows 149-215).
+tests/test_reference_image.py compares the oracle and the GPU path with these rows.
 
 The PNG is decoded here (zlib + the five PNG row filters); no image library is needed.  Re-run where the
 reference is present:   python tests/golden/make_reference_image_fixture.py /root/reference/image.png
@@ -19,7 +21,7 @@ import zlib
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROWS = 150
+ROWS = 224
 
 
 def read_png(path):
