@@ -164,7 +164,7 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_materia
  * takes 4 - 8 % longer.  RT_BUILD_AUTO takes the host builder below 65 536 spheres and the
  * device builder from there on, where the host build costs more than it saves in a render of
  * up to a few seconds. */
-enum { RT_BUILD_HOST_SAH = 0, RT_BUILD_DEVICE_LBVH = 1, RT_BUILD_AUTO = 2 };
+enum { RT_BUILD_HOST_SAH = 0, RT_BUILD_DEVICE_LBVH = 1, RT_BUILD_AUTO = 2, RT_BUILD_DEVICE_SAH = 3 };
 int rt_scene_create_ex(const rt_sphere* spheres, size_t n_spheres, const rt_material* materials, size_t n_materials, uint32_t builder,
                        rt_scene** out);
 /* `BVH::new` for a host that owns several GPUs (src/main.rs:84 builds one tree; here every device gets a copy

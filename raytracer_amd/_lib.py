@@ -72,7 +72,7 @@ SHARD_DTYPE = np.dtype([("x0", "<u4"), ("y0", "<u4"), ("x1", "<u4"), ("y1", "<u4
 PARTITION_TILES, PARTITION_SAMPLES = 0, 1
 
 LAMBERTIAN, METAL, DIELECTRIC = 0, 1, 2
-BUILD_HOST_SAH, BUILD_DEVICE_LBVH, BUILD_AUTO = 0, 1, 2
+BUILD_HOST_SAH, BUILD_DEVICE_LBVH, BUILD_AUTO, BUILD_DEVICE_SAH = 0, 1, 2, 3
 
 # Every symbol include/rt.h declares.
 EXPORTS = [

@@ -335,7 +335,7 @@ void take_out_first_leaf(const DevNode* tree_nodes, size_t n_nodes, uint32_t roo
 // ------------------------------------------------------------ scene set-up ----
 // Uploads one copy of the scene to the current device (or builds the tree there) and plans its LDS image.
 int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, size_t n_used, const std::vector<double>& mats,
-                 const std::vector<uint8_t>& material_type, bool on_device_wanted, const FlatBvh* flat_in, size_t max_depth, WideBvh* wide_cache,
+                 const std::vector<uint8_t>& material_type, bool on_device_wanted, DeviceBuilder device_builder, const FlatBvh* flat_in, size_t max_depth, WideBvh* wide_cache,
                  bool* on_device_out, uint32_t* depth_out, size_t* n_dev_nodes_out) {
   RT_HIP(hipGetDevice(&rp.device));
   hipDeviceProp_t prop;
@@ -345,7 +345,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   DeviceTree tree;
   bool on_device = false;
   if (on_device_wanted) {
-    hipError_t e = device_build_lbvh(spheres, n, material_type.data(), nm, &tree, nullptr);
+    hipError_t e = device_build(spheres, n, material_type.data(), nm, device_builder, &tree, nullptr);
     rp.d_nodes = tree.d_nodes;
     rp.d_spheres = tree.d_spheres;
     rp.d_aux = tree.d_aux;
@@ -365,7 +365,8 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   }
   const FlatBvh& flat = *flat_in;
   const size_t n_dev_nodes = on_device ? tree.n_nodes : flat.nodes.size();
-  const uint32_t tree_depth = on_device ? tree.depth : flat.depth;
+  // (levels of inner nodes: what the traversal stack must hold; the device builder counts the leaves' level too)
+  const uint32_t tree_depth = on_device ? (tree.depth > 1 ? tree.depth - 1 : 1) : flat.depth;
 
   // LDS plan for one workgroup per CU: the per-lane stacks are mandatory; then, while they
   // fit, the top of the tree, the sphere records, the slots' shading data and the materials.
@@ -514,7 +515,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   if (!wide && first_leaf != kRefNone) dev.root = walk_root;
   if (n > 0) RT_HIP(preload_render(dev));
   *on_device_out = on_device;
-  *depth_out = tree_depth;
+  *depth_out = on_device ? tree.depth : tree_depth;
   *n_dev_nodes_out = n_final_nodes;
   return RT_OK;
 }
@@ -522,7 +523,7 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
 int create_scene(const rt_sphere* spheres, size_t n, const rt_material* materials, size_t nm, uint32_t builder, const int32_t* devices,
                  size_t n_devices, bool current_device_only, rt_scene** out) {
   if (!out) return fail(RT_ERR_INVALID, "rt_scene_create: out is null");
-  if (builder > RT_BUILD_AUTO) return fail(RT_ERR_INVALID, "rt_scene_create: unknown builder");
+  if (builder > RT_BUILD_DEVICE_SAH) return fail(RT_ERR_INVALID, "rt_scene_create: unknown builder");
   if (builder == RT_BUILD_AUTO) builder = n >= kAutoDeviceBuild ? RT_BUILD_DEVICE_LBVH : RT_BUILD_HOST_SAH;
   *out = nullptr;
   if ((n && !spheres) || (nm && !materials)) return fail(RT_ERR_INVALID, "rt_scene_create: null array");
@@ -639,7 +640,8 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
   // device (two or more spheres; a tree too deep for the traversal stack falls back to the host builder).
   auto t0 = std::chrono::steady_clock::now();
   const size_t max_depth = (kLdsPerCu - lds_fixed_bytes(false) - 64 - 16 * 1024) / (kWorkgroup * 4);
-  bool want_device = builder == RT_BUILD_DEVICE_LBVH && n >= 2;
+  bool want_device = (builder == RT_BUILD_DEVICE_LBVH || builder == RT_BUILD_DEVICE_SAH) && n >= 2;
+  const DeviceBuilder device_builder = builder == RT_BUILD_DEVICE_SAH ? DeviceBuilder::kBinnedSah : DeviceBuilder::kClustering;
   FlatBvh flat;
   WideBvh wide_cache;
   bool have_flat = false;
@@ -659,7 +661,7 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
         have_flat = true;
       }
       bool od = false;
-      int rc = make_replica(*rp, spheres, n, n_table, n_used, mats, sc->material_type, want_device, &flat, max_depth, &wide_cache, &od, &tree_depth, &n_dev_nodes);
+      int rc = make_replica(*rp, spheres, n, n_table, n_used, mats, sc->material_type, want_device, device_builder, &flat, max_depth, &wide_cache, &od, &tree_depth, &n_dev_nodes);
       if (rc) return rc;
       if (want_device && !od) {  // too deep: every replica takes the host tree
         want_device = false;
@@ -696,7 +698,7 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
   sc->info.n_nodes = on_device ? 2 * n - 1 : sc->host.nodes.size();
   sc->info.n_device_nodes = n_dev_nodes;
   sc->info.depth = on_device ? tree_depth : sc->host.depth;
-  sc->info.builder = on_device ? RT_BUILD_DEVICE_LBVH : RT_BUILD_HOST_SAH;
+  sc->info.builder = on_device ? builder : (uint32_t)RT_BUILD_HOST_SAH;
   sc->info.n_nodes_in_lds = r0.dev.n_nodes_lds;
   sc->info.spheres_in_lds = (r0.dev.n_spheres_lds ? 1u : 0u) | (r0.dev.n_aux_lds ? 2u : 0u) | (r0.dev.n_materials_lds ? 4u : 0u);
   sc->info.device = (uint32_t)r0.device;

@@ -21,11 +21,15 @@ struct DeviceTree {
   float bound = 0.0f;
 };
 
-// Linear BVH over n >= 2 spheres (host array), one sphere per leaf.  material_type[m] is the kind
+// How the hierarchy is made: by clustering the spheres along their Morton order from the bottom up, or by the
+// reference's own binned surface-area splits from the top down (the host builder's tree, rt_build_sah.hip).
+enum class DeviceBuilder { kClustering, kBinnedSah };
+
+// The tree over n >= 2 spheres (host array), one sphere per leaf.  material_type[m] is the kind
 // (0..2) of material m; it is packed next to the material index in the shading data.
 // Returns when the tree is complete.
-hipError_t device_build_lbvh(const rt_sphere* spheres, size_t n, const uint8_t* material_type, size_t n_materials, DeviceTree* out,
-                             hipStream_t stream);
+hipError_t device_build(const rt_sphere* spheres, size_t n, const uint8_t* material_type, size_t n_materials, DeviceBuilder builder,
+                        DeviceTree* out, hipStream_t stream);
 
 // The four-wide tree (WideNode records, bvh_builder.h) collapsed on the device from n_two_wide two-wide nodes in
 // device memory (root = node 0), by the algorithm of collapse_wide on the host, breadth-first.  *d_wide_out is

@@ -11,16 +11,13 @@
 #include <rocprim/rocprim.hpp>
 
 #include "rt_build.h"
+#include "rt_build_internal.h"
 
 namespace rta {
 namespace {
 
 constexpr int kThreads = 256;
 constexpr uint32_t kLeafBit = 0x80000000u;
-
-struct Box6 {
-  double lo[3], hi[3];
-};
 
 __device__ __forceinline__ float round_down(double v) {
   float f = (float)v;
@@ -299,13 +296,15 @@ __global__ __launch_bounds__(kThreads) void rank_kernel(int n_inner, const uint3
 __global__ __launch_bounds__(kThreads) void emit_nodes_kernel(int n_inner, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
                                                                const uint32_t* __restrict__ new_of, const Box6* __restrict__ prim_box,
                                                                const uint32_t* __restrict__ vals, const Box6* __restrict__ node_box,
-                                                               float4* __restrict__ nodes, float* __restrict__ bound, uint32_t root) {
+                                                               float4* __restrict__ nodes, float* __restrict__ bound, uint32_t root,
+                                                               const uint8_t* __restrict__ split_axis) {
   const int i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n_inner) return;
   uint32_t r0 = left[i], r1 = right[i];
   Box6 b0 = (r0 & kLeafBit) ? prim_box[vals[r0 & ~kLeafBit]] : node_box[r0];
   Box6 b1 = (r1 & kLeafBit) ? prim_box[vals[r1 & ~kLeafBit]] : node_box[r1];
-  // split axis: where the children's centres are furthest apart; child 0 is the lower one, as in the host tree
+  // split axis: the builder's, with its order of the children (child 0 holds the lower buckets); where it has none to
+  // give, the axis along which the children's centres are furthest apart, child 0 the lower one, as in the host tree
   int axis = 0;
   double best = -1.0, diff[3];
   for (int a = 0; a < 3; ++a) {
@@ -315,7 +314,9 @@ __global__ __launch_bounds__(kThreads) void emit_nodes_kernel(int n_inner, const
       axis = a;
     }
   }
-  if (diff[axis] < 0.0) {
+  const bool given = split_axis && split_axis[i] < 3;
+  if (given) axis = split_axis[i];
+  if (!given && diff[axis] < 0.0) {
     const Box6 tb = b0;
     b0 = b1;
     b1 = tb;
@@ -505,8 +506,8 @@ hipError_t device_collapse_wide(const void* d_two_wide_nodes, uint32_t n_two_wid
   return hipSuccess;
 }
 
-hipError_t device_build_lbvh(const rt_sphere* h_spheres, size_t n_, const uint8_t* h_material_type, size_t n_materials, DeviceTree* out,
-                             hipStream_t stream) {
+hipError_t device_build(const rt_sphere* h_spheres, size_t n_, const uint8_t* h_material_type, size_t n_materials, DeviceBuilder builder,
+                        DeviceTree* out, hipStream_t stream) {
   const uint32_t n = (uint32_t)n_;
   const uint32_t n_inner = n - 1;  // the caller guarantees n >= 2
   const unsigned blocks = (n + kThreads - 1) / kThreads, blocks_inner = (n_inner + kThreads - 1) / kThreads;
@@ -537,21 +538,9 @@ hipError_t device_build_lbvh(const rt_sphere* h_spheres, size_t n_, const uint8_
   RTB(ids.alloc((size_t)n_inner * 4));
   RTB(order.alloc((size_t)n_inner * 4));
   RTB(new_of.alloc((size_t)n_inner * 4));
-  RTB(misc.alloc(16));  // [0] deepest level (u32), [1] bound (f32)
+  RTB(misc.alloc(16));  // [0] deepest level (u32), [1] bound (f32), [2] the root's id (surface-area build)
   RTB(hipMemsetAsync(arrivals.p, 0, (size_t)n_inner * 4, stream));
   RTB(hipMemsetAsync(misc.p, 0, 16, stream));
-
-  // boxes and their bounds; which spheres stand apart; the centroid bounds of the others; Morton codes
-  hipLaunchKernelGGL(boxes_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, prim_box.as<Box6>(), centroid.as<double>(),
-                     (const uint8_t*)nullptr, block_bounds.as<double>());
-  hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(kThreads), 0, stream, block_bounds.as<double>(), blocks, bounds.as<double>());
-  hipLaunchKernelGGL(flag_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, bounds.as<double>(), flags.as<uint8_t>());
-  hipLaunchKernelGGL(boxes_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, prim_box.as<Box6>(), centroid.as<double>(),
-                     flags.as<uint8_t>(), block_bounds.as<double>());
-  hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(kThreads), 0, stream, block_bounds.as<double>(), blocks, bounds.as<double>());
-  hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(kThreads), 0, stream, centroid.as<double>(), bounds.as<double>(), flags.as<uint8_t>(), n,
-                     keys.as<uint64_t>(), vals.as<uint32_t>());
-  RTB(hipGetLastError());
 
   size_t tmp_bytes = 0, tmp_bytes2 = 0;
   RTB(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), n, 0, 64,
@@ -559,52 +548,81 @@ hipError_t device_build_lbvh(const rt_sphere* h_spheres, size_t n_, const uint8_
   RTB(rocprim::radix_sort_pairs(nullptr, tmp_bytes2, level.as<uint32_t>(), level2.as<uint32_t>(), ids.as<uint32_t>(), order.as<uint32_t>(), n_inner,
                                 0, 8, stream));
   RTB(sort_tmp.alloc(tmp_bytes > tmp_bytes2 ? tmp_bytes : tmp_bytes2));
-  RTB(rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), n, 0, 64,
-                                stream));
 
-  // clustering rounds over the Morton order (ping-pong arrays; the host reads the two counts back after every round)
-  Scratch ref_a, ref_b, box_a, box_b, nearest, marks, scan, totals;
-  RTB(ref_a.alloc((size_t)n * 4));
-  RTB(ref_b.alloc((size_t)n * 4));
-  RTB(box_a.alloc((size_t)n * sizeof(ClusterBox)));
-  RTB(box_b.alloc((size_t)n * sizeof(ClusterBox)));
-  RTB(nearest.alloc((size_t)n * 4));
-  RTB(marks.alloc((size_t)n * 8));
-  RTB(scan.alloc((size_t)n * 8));
-  RTB(totals.alloc(8));
-  size_t scan_bytes = 0;
-  RTB(rocprim::exclusive_scan(nullptr, scan_bytes, marks.as<unsigned long long>(), scan.as<unsigned long long>(), 0ull, n,
-                              rocprim::plus<unsigned long long>(), stream));
-  Scratch scan_tmp;
-  RTB(scan_tmp.alloc(scan_bytes));
-  hipLaunchKernelGGL(ploc_init_kernel, dim3(blocks), dim3(kThreads), 0, stream, prim_box.as<Box6>(), vals2.as<uint32_t>(), n, ref_a.as<uint32_t>(),
-                     box_a.as<ClusterBox>());
-  uint32_t m = n, next_id = 0, root_id = 0;
-  Scratch *ref_in = &ref_a, *ref_out = &ref_b, *box_in = &box_a, *box_out = &box_b;
-  while (m > 1) {
-    const unsigned bm = (m + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(ploc_nearest_kernel, dim3(bm), dim3(kThreads), 0, stream, box_in->as<ClusterBox>(), (int)m, nearest.as<uint32_t>());
-    hipLaunchKernelGGL(ploc_mark_kernel, dim3(bm), dim3(kThreads), 0, stream, nearest.as<uint32_t>(), (int)m, marks.as<unsigned long long>());
-    size_t bytes = scan_bytes;
-    RTB(rocprim::exclusive_scan(scan_tmp.p, bytes, marks.as<unsigned long long>(), scan.as<unsigned long long>(), 0ull, m,
-                                rocprim::plus<unsigned long long>(), stream));
-    hipLaunchKernelGGL(ploc_merge_kernel, dim3(bm), dim3(kThreads), 0, stream, ref_in->as<uint32_t>(), box_in->as<ClusterBox>(),
-                       nearest.as<uint32_t>(), marks.as<unsigned long long>(), scan.as<unsigned long long>(), (int)m, next_id,
-                       ref_out->as<uint32_t>(), box_out->as<ClusterBox>(), left.as<uint32_t>(), right.as<uint32_t>(), parent_inner.as<uint32_t>(),
-                       parent_leaf.as<uint32_t>(), totals.as<unsigned long long>());
+  Scratch split_axis;
+  uint32_t root_id = 0;
+  const bool sah = builder == DeviceBuilder::kBinnedSah;
+  if (sah) {
+    // boxes and centroids, then the hierarchy of the reference's own algorithm (rt_build_sah.hip); leaf k is sphere vals2[k]
+    RTB(split_axis.alloc(n_inner));
+    hipLaunchKernelGGL(boxes_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, prim_box.as<Box6>(), centroid.as<double>(),
+                       (const uint8_t*)nullptr, block_bounds.as<double>());
     RTB(hipGetLastError());
-    unsigned long long t = 0;
-    RTB(hipMemcpyAsync(&t, totals.p, 8, hipMemcpyDeviceToHost, stream));
+    RTB(sah_hierarchy(prim_box.as<Box6>(), centroid.as<double>(), n, left.as<uint32_t>(), right.as<uint32_t>(), parent_inner.as<uint32_t>(),
+                      parent_leaf.as<uint32_t>(), split_axis.as<uint8_t>(), vals2.as<uint32_t>(), misc.as<uint32_t>() + 2, stream));
+    RTB(hipMemcpyAsync(&root_id, misc.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost, stream));
     RTB(hipStreamSynchronize(stream));
-    const uint32_t left_over = (uint32_t)t, made = (uint32_t)(t >> 32);
-    if (made == 0 || left_over + made != m) return hipErrorUnknown;  // (every round merges at least the closest pair)
-    next_id += made;
-    m = left_over;
-    std::swap(ref_in, ref_out);
-    std::swap(box_in, box_out);
+    if (root_id >= n_inner) return hipErrorUnknown;
+  } else {
+    // boxes and their bounds; which spheres stand apart; the centroid bounds of the others; Morton codes
+    hipLaunchKernelGGL(boxes_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, prim_box.as<Box6>(), centroid.as<double>(),
+                       (const uint8_t*)nullptr, block_bounds.as<double>());
+    hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(kThreads), 0, stream, block_bounds.as<double>(), blocks, bounds.as<double>());
+    hipLaunchKernelGGL(flag_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, bounds.as<double>(), flags.as<uint8_t>());
+    hipLaunchKernelGGL(boxes_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, prim_box.as<Box6>(), centroid.as<double>(),
+                       flags.as<uint8_t>(), block_bounds.as<double>());
+    hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(kThreads), 0, stream, block_bounds.as<double>(), blocks, bounds.as<double>());
+    hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(kThreads), 0, stream, centroid.as<double>(), bounds.as<double>(), flags.as<uint8_t>(), n,
+                       keys.as<uint64_t>(), vals.as<uint32_t>());
+    RTB(hipGetLastError());
+
+    RTB(rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<uint32_t>(), vals2.as<uint32_t>(), n, 0, 64,
+                                  stream));
+
+    // clustering rounds over the Morton order (ping-pong arrays; the host reads the two counts back after every round)
+    Scratch ref_a, ref_b, box_a, box_b, nearest, marks, scan, totals;
+    RTB(ref_a.alloc((size_t)n * 4));
+    RTB(ref_b.alloc((size_t)n * 4));
+    RTB(box_a.alloc((size_t)n * sizeof(ClusterBox)));
+    RTB(box_b.alloc((size_t)n * sizeof(ClusterBox)));
+    RTB(nearest.alloc((size_t)n * 4));
+    RTB(marks.alloc((size_t)n * 8));
+    RTB(scan.alloc((size_t)n * 8));
+    RTB(totals.alloc(8));
+    size_t scan_bytes = 0;
+    RTB(rocprim::exclusive_scan(nullptr, scan_bytes, marks.as<unsigned long long>(), scan.as<unsigned long long>(), 0ull, n,
+                                rocprim::plus<unsigned long long>(), stream));
+    Scratch scan_tmp;
+    RTB(scan_tmp.alloc(scan_bytes));
+    hipLaunchKernelGGL(ploc_init_kernel, dim3(blocks), dim3(kThreads), 0, stream, prim_box.as<Box6>(), vals2.as<uint32_t>(), n, ref_a.as<uint32_t>(),
+                       box_a.as<ClusterBox>());
+    uint32_t m = n, next_id = 0;
+    Scratch *ref_in = &ref_a, *ref_out = &ref_b, *box_in = &box_a, *box_out = &box_b;
+    while (m > 1) {
+      const unsigned bm = (m + kThreads - 1) / kThreads;
+      hipLaunchKernelGGL(ploc_nearest_kernel, dim3(bm), dim3(kThreads), 0, stream, box_in->as<ClusterBox>(), (int)m, nearest.as<uint32_t>());
+      hipLaunchKernelGGL(ploc_mark_kernel, dim3(bm), dim3(kThreads), 0, stream, nearest.as<uint32_t>(), (int)m, marks.as<unsigned long long>());
+      size_t bytes = scan_bytes;
+      RTB(rocprim::exclusive_scan(scan_tmp.p, bytes, marks.as<unsigned long long>(), scan.as<unsigned long long>(), 0ull, m,
+                                  rocprim::plus<unsigned long long>(), stream));
+      hipLaunchKernelGGL(ploc_merge_kernel, dim3(bm), dim3(kThreads), 0, stream, ref_in->as<uint32_t>(), box_in->as<ClusterBox>(),
+                         nearest.as<uint32_t>(), marks.as<unsigned long long>(), scan.as<unsigned long long>(), (int)m, next_id,
+                         ref_out->as<uint32_t>(), box_out->as<ClusterBox>(), left.as<uint32_t>(), right.as<uint32_t>(), parent_inner.as<uint32_t>(),
+                         parent_leaf.as<uint32_t>(), totals.as<unsigned long long>());
+      RTB(hipGetLastError());
+      unsigned long long t = 0;
+      RTB(hipMemcpyAsync(&t, totals.p, 8, hipMemcpyDeviceToHost, stream));
+      RTB(hipStreamSynchronize(stream));
+      const uint32_t left_over = (uint32_t)t, made = (uint32_t)(t >> 32);
+      if (made == 0 || left_over + made != m) return hipErrorUnknown;  // (every round merges at least the closest pair)
+      next_id += made;
+      m = left_over;
+      std::swap(ref_in, ref_out);
+      std::swap(box_in, box_out);
+    }
+    if (next_id != n_inner) return hipErrorUnknown;
+    root_id = n_inner - 1;  // the last node made
   }
-  if (next_id != n_inner) return hipErrorUnknown;
-  root_id = n_inner - 1;  // the last node made
   hipLaunchKernelGGL(fit_kernel, dim3(blocks), dim3(kThreads), 0, stream, (int)n, left.as<uint32_t>(), right.as<uint32_t>(),
                      parent_inner.as<uint32_t>(), parent_leaf.as<uint32_t>(), prim_box.as<Box6>(), vals2.as<uint32_t>(), node_box.as<Box6>(),
                      arrivals.as<uint32_t>());
@@ -621,7 +639,7 @@ hipError_t device_build_lbvh(const rt_sphere* h_spheres, size_t n_, const uint8_
   RTB(hipMalloc(&out->d_aux, (size_t)n * 16));
   hipLaunchKernelGGL(emit_nodes_kernel, dim3(blocks_inner), dim3(kThreads), 0, stream, (int)n_inner, left.as<uint32_t>(), right.as<uint32_t>(),
                      new_of.as<uint32_t>(), prim_box.as<Box6>(), vals2.as<uint32_t>(), node_box.as<Box6>(), static_cast<float4*>(out->d_nodes),
-                     misc.as<float>() + 1, root_id);
+                     misc.as<float>() + 1, root_id, sah ? split_axis.as<uint8_t>() : (const uint8_t*)nullptr);
   hipLaunchKernelGGL(emit_spheres_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), vals2.as<uint32_t>(), n,
                      d_mtype.as<uint8_t>(), static_cast<double*>(out->d_spheres), static_cast<double2*>(out->d_aux));
   RTB(hipGetLastError());
