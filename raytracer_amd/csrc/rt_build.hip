@@ -559,7 +559,7 @@ hipError_t device_build(const rt_sphere* h_spheres, size_t n_, const uint8_t* h_
                        (const uint8_t*)nullptr, block_bounds.as<double>());
     RTB(hipGetLastError());
     RTB(sah_hierarchy(prim_box.as<Box6>(), centroid.as<double>(), n, left.as<uint32_t>(), right.as<uint32_t>(), parent_inner.as<uint32_t>(),
-                      parent_leaf.as<uint32_t>(), split_axis.as<uint8_t>(), vals2.as<uint32_t>(), misc.as<uint32_t>() + 2, stream));
+                      parent_leaf.as<uint32_t>(), split_axis.as<uint8_t>(), node_box.as<Box6>(), vals2.as<uint32_t>(), misc.as<uint32_t>() + 2, stream));
     RTB(hipMemcpyAsync(&root_id, misc.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost, stream));
     RTB(hipStreamSynchronize(stream));
     if (root_id >= n_inner) return hipErrorUnknown;
@@ -623,9 +623,10 @@ hipError_t device_build(const rt_sphere* h_spheres, size_t n_, const uint8_t* h_
     if (next_id != n_inner) return hipErrorUnknown;
     root_id = n_inner - 1;  // the last node made
   }
-  hipLaunchKernelGGL(fit_kernel, dim3(blocks), dim3(kThreads), 0, stream, (int)n, left.as<uint32_t>(), right.as<uint32_t>(),
-                     parent_inner.as<uint32_t>(), parent_leaf.as<uint32_t>(), prim_box.as<Box6>(), vals2.as<uint32_t>(), node_box.as<Box6>(),
-                     arrivals.as<uint32_t>());
+  if (!sah)  // (the surface-area build knows every node's box already)
+    hipLaunchKernelGGL(fit_kernel, dim3(blocks), dim3(kThreads), 0, stream, (int)n, left.as<uint32_t>(), right.as<uint32_t>(),
+                       parent_inner.as<uint32_t>(), parent_leaf.as<uint32_t>(), prim_box.as<Box6>(), vals2.as<uint32_t>(), node_box.as<Box6>(),
+                       arrivals.as<uint32_t>());
   hipLaunchKernelGGL(level_kernel, dim3(blocks_inner), dim3(kThreads), 0, stream, (int)n_inner, parent_inner.as<uint32_t>(), level.as<uint32_t>(),
                      ids.as<uint32_t>(), misc.as<uint32_t>());
   RTB(hipGetLastError());

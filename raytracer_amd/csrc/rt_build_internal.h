@@ -18,8 +18,9 @@ struct Box6 {
 // the same boxes, buckets, costs and stable partitions as the host builder (bvh_builder.cpp), so the same tree.  Where
 // the reference would stop and make a leaf of several spheres (no split cheaper than the leaf: spheres on top of each
 // other), the segment is cut in the middle instead.  prim_box and centroid: Sphere::aabb and its centroid per sphere.
-// axis[id]: the axis the node was split along (child 0 holds the lower buckets).  *root_id: the root's id.
+// axis[id]: the axis the node was split along (child 0 holds the lower buckets); node_box[id]: the node's box (the union
+// of its spheres' boxes: what fitting the boxes bottom-up would give).  *root_id: the root's id.
 hipError_t sah_hierarchy(const Box6* prim_box, const double* centroid, uint32_t n, uint32_t* left, uint32_t* right, uint32_t* parent_inner,
-                         uint32_t* parent_leaf, uint8_t* axis, uint32_t* order, uint32_t* root_id, hipStream_t stream);
+                         uint32_t* parent_leaf, uint8_t* axis, Box6* node_box, uint32_t* order, uint32_t* root_id, hipStream_t stream);
 
 }  // namespace rta

@@ -23,7 +23,7 @@ namespace {
 constexpr int kBuckets = 32;              // src/bvh.rs:89
 constexpr double kLeafCost = 1.0;         // src/bvh.rs:87
 constexpr double kSplitCost = 1.0 / 8.0;  // src/bvh.rs:88
-constexpr uint32_t kSmall = 512;          // segments up to this size are finished by one wave
+constexpr uint32_t kSmall = 128;          // segments up to this size are finished by one wave
 constexpr uint32_t kChunk = 2048;         // positions of a large segment that one block works on
 constexpr int kBlock = 256;
 constexpr uint32_t kNone = 0xffffffffu, kLeafBit = 0x80000000u;
@@ -198,9 +198,13 @@ __device__ __forceinline__ void hist_add(Hist* h, int a, int bucket, const Box6&
 struct Links {
   uint32_t *left, *right, *parent_inner, *parent_leaf, *order, *root_id;
   uint8_t* axis;
+  Box6* node_box;
 };
-__device__ __forceinline__ uint32_t make_node(const Links& L, const Seg& s, const Decision& d) {
+__device__ __forceinline__ uint32_t make_node(const Links& L, const Seg& s, const Decision& d, const double lo[3], const double hi[3]) {
   const uint32_t id = s.lo + d.nl - 1u;
+  Box6 box;
+  for (int a = 0; a < 3; ++a) box.lo[a] = lo[a], box.hi[a] = hi[a];
+  L.node_box[id] = box;
   if (s.parent != kNone)
     ((s.side & 1u) ? L.right : L.left)[s.parent] = id;
   else
@@ -209,10 +213,10 @@ __device__ __forceinline__ uint32_t make_node(const Links& L, const Seg& s, cons
   L.axis[id] = (uint8_t)(d.sah ? d.axis : 3);
   return id;
 }
-__device__ __forceinline__ void make_leaf(const Links& L, uint32_t id, uint32_t side, uint32_t pos, const uint32_t* arr) {
+// (the leaf's sphere, order[pos], is written by whoever moved it there)
+__device__ __forceinline__ void make_leaf(const Links& L, uint32_t id, uint32_t side, uint32_t pos) {
   (side ? L.right : L.left)[id] = kLeafBit | pos;
   L.parent_leaf[pos] = id;
-  L.order[pos] = arr[pos];
 }
 
 // ------------------------------------------------------------ small segments ----
@@ -253,14 +257,14 @@ __global__ __launch_bounds__(64) void small_kernel(const Seg* __restrict__ roots
             swap = c1 < c0;
           }
         }
+        double lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) lo[a] = fmin(b0.lo[a], b1.lo[a]), hi[a] = fmax(b0.hi[a], b1.hi[a]);
         if (d.sah) {
-          double lo[3], hi[3];
-          for (int a = 0; a < 3; ++a) lo[a] = fmin(b0.lo[a], b1.lo[a]), hi[a] = fmax(b0.hi[a], b1.hi[a]);
           const Box6 &first = swap ? b1 : b0, &second = swap ? b0 : b1;
           const double cost = kSplitCost + kLeafCost * ((double)1u * surface_area(first.lo, first.hi) + (double)1u * surface_area(second.lo, second.hi)) / surface_area(lo, hi);
           if (!(cost < kLeafCost * (double)2u)) d.sah = swap = false;  // src/bvh.rs:124: the reference keeps the two in one leaf; here they stay as they are
         }
-        const uint32_t id = make_node(L, s, d);
+        const uint32_t id = make_node(L, s, d, lo, hi);
         L.left[id] = kLeafBit | s.lo;
         L.right[id] = kLeafBit | (s.lo + 1u);
         L.parent_leaf[s.lo] = L.parent_leaf[s.lo + 1u] = id;
@@ -270,11 +274,24 @@ __global__ __launch_bounds__(64) void small_kernel(const Seg* __restrict__ roots
       lane_sync();
       continue;
     }
+    // The first 64 spheres of the segment stay in registers through the three passes (bounds, histogram, partition):
+    // most segments have no more.  The index arrays are read and written past the L1 cache (other lanes wrote them).
+    const uint32_t p0 = s.lo + lane;
+    const bool have0 = p0 < s.hi;
+    const uint32_t prim0 = have0 ? __builtin_nontemporal_load(in + p0) : 0u;
+    Box6 box0;
+    double c0[3];
+    if (have0) {
+      box0 = prim_box[prim0];
+      for (int a = 0; a < 3; ++a) c0[a] = centroid[3 * (size_t)prim0 + a];
+    } else {
+      for (int a = 0; a < 3; ++a) box0.lo[a] = c0[a] = __builtin_inf(), box0.hi[a] = -__builtin_inf();
+    }
     // bounds of the boxes and of the centroids (AABB::bounding_box, src/aabb.rs:40-46)
     Bounds b;
-    for (int a = 0; a < 3; ++a) b.lo[a] = b.cmin[a] = __builtin_inf(), b.hi[a] = b.cmax[a] = -__builtin_inf();
-    for (uint32_t p = s.lo + lane; p < s.hi; p += 64u) {
-      const uint32_t prim = in[p];
+    for (int a = 0; a < 3; ++a) b.lo[a] = box0.lo[a], b.hi[a] = box0.hi[a], b.cmin[a] = have0 ? c0[a] : __builtin_inf(), b.cmax[a] = have0 ? c0[a] : -__builtin_inf();
+    for (uint32_t p = p0 + 64u; p < s.hi; p += 64u) {
+      const uint32_t prim = __builtin_nontemporal_load(in + p);
       const Box6 box = prim_box[prim];
       for (int a = 0; a < 3; ++a) {
         const double c = centroid[3 * (size_t)prim + a];
@@ -284,59 +301,72 @@ __global__ __launch_bounds__(64) void small_kernel(const Seg* __restrict__ roots
         b.cmax[a] = fmax(b.cmax[a], c);
       }
     }
-    for (int off = 32; off > 0; off >>= 1)
-      for (int a = 0; a < 3; ++a) {
-        b.lo[a] = fmin(b.lo[a], __shfl_xor(b.lo[a], off));
-        b.hi[a] = fmax(b.hi[a], __shfl_xor(b.hi[a], off));
-        b.cmin[a] = fmin(b.cmin[a], __shfl_xor(b.cmin[a], off));
-        b.cmax[a] = fmax(b.cmax[a], __shfl_xor(b.cmax[a], off));
-      }
+    for (int off = 32; off > 0; off >>= 1) {
+      b.lo[0] = fmin(b.lo[0], __shfl_xor(b.lo[0], off)), b.lo[1] = fmin(b.lo[1], __shfl_xor(b.lo[1], off)), b.lo[2] = fmin(b.lo[2], __shfl_xor(b.lo[2], off));
+      b.hi[0] = fmax(b.hi[0], __shfl_xor(b.hi[0], off)), b.hi[1] = fmax(b.hi[1], __shfl_xor(b.hi[1], off)), b.hi[2] = fmax(b.hi[2], __shfl_xor(b.hi[2], off));
+      b.cmin[0] = fmin(b.cmin[0], __shfl_xor(b.cmin[0], off)), b.cmin[1] = fmin(b.cmin[1], __shfl_xor(b.cmin[1], off)), b.cmin[2] = fmin(b.cmin[2], __shfl_xor(b.cmin[2], off));
+      b.cmax[0] = fmax(b.cmax[0], __shfl_xor(b.cmax[0], off)), b.cmax[1] = fmax(b.cmax[1], __shfl_xor(b.cmax[1], off)), b.cmax[2] = fmax(b.cmax[2], __shfl_xor(b.cmax[2], off));
+    }
     hist_clear(&h, lane, 64u);
     lane_sync();
-    for (uint32_t p = s.lo + lane; p < s.hi; p += 64u) {
-      const uint32_t prim = in[p];
+    if (have0) {
+      if ((b.cmax[0] - b.cmin[0]) > 0.0) hist_add(&h, 0, choose_bucket(b.cmin[0], b.cmax[0], c0[0]), box0);
+      if ((b.cmax[1] - b.cmin[1]) > 0.0) hist_add(&h, 1, choose_bucket(b.cmin[1], b.cmax[1], c0[1]), box0);
+      if ((b.cmax[2] - b.cmin[2]) > 0.0) hist_add(&h, 2, choose_bucket(b.cmin[2], b.cmax[2], c0[2]), box0);
+    }
+    for (uint32_t p = p0 + 64u; p < s.hi; p += 64u) {
+      const uint32_t prim = __builtin_nontemporal_load(in + p);
       const Box6 box = prim_box[prim];
       for (int a = 0; a < 3; ++a)
         if ((b.cmax[a] - b.cmin[a]) > 0.0) hist_add(&h, a, choose_bucket(b.cmin[a], b.cmax[a], centroid[3 * (size_t)prim + a]), box);
     }
     lane_sync();
     const Decision d = pick_split(&h, b, n, &sw, lane);
-    const uint32_t* arr = in;  // where the segment is after the partition
+    const uint32_t mid = s.lo + d.nl;
+    const bool leaf_left = d.nl == 1u, leaf_right = s.hi - mid == 1u;
     uint32_t newbuf = buf;
-    if (d.sah) {  // stable partition into the other array
+    if (d.sah) {  // stable partition into the other array; a sphere that ends up alone is a leaf: its place in the final order is written here
       uint32_t n_left = 0, n_right = 0;
-      const double cmin = b.cmin[d.axis], cmax = b.cmax[d.axis];
+      const double cmin = d.axis == 0 ? b.cmin[0] : d.axis == 1 ? b.cmin[1] : b.cmin[2], cmax = d.axis == 0 ? b.cmax[0] : d.axis == 1 ? b.cmax[1] : b.cmax[2];
       for (uint32_t base = s.lo; base < s.hi; base += 64u) {
         const uint32_t p = base + lane;
-        const bool act = p < s.hi;
-        const uint32_t prim = act ? in[p] : 0u;
-        const bool to_left = act && choose_bucket(cmin, cmax, centroid[3 * (size_t)prim + d.axis]) < d.split;
+        const bool act = p < s.hi, first = base == s.lo;
+        const uint32_t prim = first ? prim0 : (act ? __builtin_nontemporal_load(in + p) : 0u);
+        const double c = first ? (d.axis == 0 ? c0[0] : d.axis == 1 ? c0[1] : c0[2]) : (act ? centroid[3 * (size_t)prim + d.axis] : 0.0);
+        const bool to_left = act && choose_bucket(cmin, cmax, c) < d.split;
         const unsigned long long m_left = __ballot(to_left), m_right = __ballot(act && !to_left);
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (act) out[to_left ? s.lo + n_left + (uint32_t)__popcll(m_left & below) : s.lo + d.nl + n_right + (uint32_t)__popcll(m_right & below)] = prim;
+        if (act) {
+          const uint32_t dest = to_left ? s.lo + n_left + (uint32_t)__popcll(m_left & below) : mid + n_right + (uint32_t)__popcll(m_right & below);
+          __builtin_nontemporal_store(prim, out + dest);
+          if (to_left ? leaf_left : leaf_right) L.order[dest] = prim;
+        }
         n_left += (uint32_t)__popcll(m_left);
         n_right += (uint32_t)__popcll(m_right);
       }
-      __threadfence();  // the other lanes read these words from now on
-      arr = out;
       newbuf = buf ^ 1u;
+    } else {  // cut in the middle, nothing moves
+      if (leaf_left && lane == 0) L.order[s.lo] = prim0;
+      if (leaf_right) {
+        const uint32_t last = s.hi - 1u;
+        if (((last - s.lo) & 63u) == lane) L.order[last] = last - s.lo < 64u ? prim0 : __builtin_nontemporal_load(in + last);
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the stores above before the loads of the next round (one wave: program order does the rest)
     lane_sync();
     if (lane == 0) {
-      const uint32_t id = make_node(L, s, d);
-      const uint32_t mid = s.lo + d.nl;
+      const uint32_t id = make_node(L, s, d, b.lo, b.hi);
       // child 1 first, so that child 0 is taken off the stack first
-      if (s.hi - mid == 1u)
-        make_leaf(L, id, 1u, mid, arr);
+      if (leaf_right)
+        make_leaf(L, id, 1u, mid);
       else
         stack[sp] = Seg{mid, s.hi, id, 1u | (newbuf << 1)};
-      const int pushed_right = s.hi - mid == 1u ? 0 : 1;
-      if (d.nl == 1u)
-        make_leaf(L, id, 0u, s.lo, arr);
+      if (leaf_left)
+        make_leaf(L, id, 0u, s.lo);
       else
-        stack[sp + pushed_right] = Seg{s.lo, mid, id, 0u | (newbuf << 1)};
+        stack[sp + (leaf_right ? 0 : 1)] = Seg{s.lo, mid, id, 0u | (newbuf << 1)};
     }
-    sp += (s.hi - (s.lo + d.nl) == 1u ? 0 : 1) + (d.nl == 1u ? 0 : 1);
+    sp += (leaf_right ? 0 : 1) + (leaf_left ? 0 : 1);
     lane_sync();
   }
 }
@@ -461,7 +491,7 @@ __global__ __launch_bounds__(64) void big_decide_kernel(const Seg* __restrict__ 
     out.d = d;
     out.cmin = b.cmin[d.axis];
     out.cmax = b.cmax[d.axis];
-    out.id = make_node(L, s, d);
+    out.id = make_node(L, s, d, b.lo, b.hi);
     dec[k] = out;
   }
 }
@@ -490,17 +520,16 @@ __global__ __launch_bounds__(kBlock) void big_count_kernel(const Seg* __restrict
   if (threadIdx.x == 0) chunk_left[blockIdx.x] = total;
 }
 
-// chunk_left -> the number of spheres that go to child 0 in the chunks of the same segment before each chunk (one thread:
-// a level has a few thousand chunks at most).
-__global__ void big_offsets_kernel(uint32_t n_segs, const uint32_t* __restrict__ chunk_off, uint32_t* __restrict__ chunk_left) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  for (uint32_t k = 0; k < n_segs; ++k) {
-    uint32_t run = 0;
-    for (uint32_t c = chunk_off[k]; c < chunk_off[k + 1]; ++c) {
-      const uint32_t v = chunk_left[c];
-      chunk_left[c] = run;
-      run += v;
-    }
+// chunk_left -> the number of spheres that go to child 0 in the chunks of the same segment before each chunk (a thread per
+// segment: few segments have more than a chunk or two).
+__global__ __launch_bounds__(kBlock) void big_offsets_kernel(uint32_t n_segs, const uint32_t* __restrict__ chunk_off, uint32_t* __restrict__ chunk_left) {
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n_segs) return;
+  uint32_t run = 0;
+  for (uint32_t c = chunk_off[k]; c < chunk_off[k + 1]; ++c) {
+    const uint32_t v = chunk_left[c];
+    chunk_left[c] = run;
+    run += v;
   }
 }
 
@@ -558,8 +587,10 @@ __global__ __launch_bounds__(kBlock) void big_children_kernel(const Seg* __restr
   const uint32_t mid = s.lo + bd.d.nl;
   for (uint32_t side = 0; side < 2u; ++side) {
     const uint32_t lo = side ? mid : s.lo, hi = side ? s.hi : mid;
-    if (hi - lo == 1u)
-      make_leaf(L, bd.id, side, lo, arr);
+    if (hi - lo == 1u) {
+      make_leaf(L, bd.id, side, lo);
+      L.order[lo] = arr[lo];
+    }
     else if (hi - lo <= kSmall)
       small[atomicAdd(&counts[1], 1u)] = Seg{lo, hi, bd.id, side | (buf << 1)};
     else
@@ -567,17 +598,32 @@ __global__ __launch_bounds__(kBlock) void big_children_kernel(const Seg* __restr
   }
 }
 
-// chunk_off for the next level's segments; counts[2] = the number of chunks.
-__global__ void big_plan_kernel(const Seg* __restrict__ segs, uint32_t* __restrict__ chunk_off, uint32_t* counts) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  const uint32_t n_segs = counts[0];
-  uint32_t run = 0;
-  for (uint32_t k = 0; k < n_segs; ++k) {
+// chunk_off for the next level's segments; counts[2] = the number of chunks.  One block: thread t sums the chunks of a run of
+// consecutive segments, the runs' totals are scanned in LDS, and each thread writes its segments' offsets.
+constexpr int kPlanThreads = 1024;
+__global__ __launch_bounds__(kPlanThreads) void big_plan_kernel(const Seg* __restrict__ segs, uint32_t* __restrict__ chunk_off, uint32_t* counts) {
+  __shared__ uint32_t sums[kPlanThreads];
+  const uint32_t n_segs = counts[0], per = (n_segs + kPlanThreads - 1u) / kPlanThreads;
+  const uint32_t first = threadIdx.x * per, last = min(first + per, n_segs);
+  uint32_t mine = 0;
+  for (uint32_t k = first; k < last; ++k) mine += (segs[k].hi - segs[k].lo + kChunk - 1u) / kChunk;
+  sums[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 1; off < kPlanThreads; off <<= 1) {
+    const uint32_t v = (int)threadIdx.x >= off ? sums[threadIdx.x - off] : 0u;
+    __syncthreads();
+    sums[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = sums[threadIdx.x] - mine;
+  for (uint32_t k = first; k < last; ++k) {
     chunk_off[k] = run;
     run += (segs[k].hi - segs[k].lo + kChunk - 1u) / kChunk;
   }
-  chunk_off[n_segs] = run;
-  counts[2] = run;
+  if (threadIdx.x == kPlanThreads - 1) {
+    chunk_off[n_segs] = sums[kPlanThreads - 1];
+    counts[2] = sums[kPlanThreads - 1];
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void iota_kernel(uint32_t* __restrict__ idx, uint32_t n) {
@@ -606,7 +652,7 @@ struct Scratch {
 }  // namespace
 
 hipError_t sah_hierarchy(const Box6* prim_box, const double* centroid, uint32_t n, uint32_t* left, uint32_t* right, uint32_t* parent_inner,
-                         uint32_t* parent_leaf, uint8_t* axis, uint32_t* order, uint32_t* root_id, hipStream_t stream) {
+                         uint32_t* parent_leaf, uint8_t* axis, Box6* node_box, uint32_t* order, uint32_t* root_id, hipStream_t stream) {
   if (n < 2) return hipErrorInvalidValue;
   const uint32_t max_big = n / kSmall + 2, max_small = n / 2 + 2, max_chunks = n / kChunk + max_big + 2;
   Scratch idx0, idx1, segs_a, segs_b, small, acc, dec, chunk_off, chunk_left, counts;
@@ -622,7 +668,7 @@ hipError_t sah_hierarchy(const Box6* prim_box, const double* centroid, uint32_t 
   RTB(counts.alloc(16));  // [0] segments of the next level, [1] segments for the small kernel, [2] chunks of the next level
   RTB(hipMemsetAsync(counts.p, 0, 16, stream));
   hipLaunchKernelGGL(iota_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, idx0.as<uint32_t>(), n);  // ascending sphere order, as on the host
-  const Links L{left, right, parent_inner, parent_leaf, order, root_id, axis};
+  const Links L{left, right, parent_inner, parent_leaf, order, root_id, axis, node_box};
 
   const Seg root{0u, n, kNone, 0u};
   uint32_t n_segs = 0, n_chunks = 0, n_small = 0;
@@ -650,13 +696,13 @@ hipError_t sah_hierarchy(const Box6* prim_box, const double* centroid, uint32_t 
     hipLaunchKernelGGL(big_decide_kernel, dim3(n_segs), dim3(64), 0, stream, cur->as<Seg>(), n_segs, acc.as<BigAcc>(), dec.as<BigDecision>(), L);
     hipLaunchKernelGGL(big_count_kernel, dim3(n_chunks), dim3(kBlock), 0, stream, cur->as<Seg>(), n_segs, chunk_off.as<uint32_t>(),
                        dec.as<BigDecision>(), centroid, in, chunk_left.as<uint32_t>());
-    hipLaunchKernelGGL(big_offsets_kernel, dim3(1), dim3(1), 0, stream, n_segs, chunk_off.as<uint32_t>(), chunk_left.as<uint32_t>());
+    hipLaunchKernelGGL(big_offsets_kernel, dim3((n_segs + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, n_segs, chunk_off.as<uint32_t>(), chunk_left.as<uint32_t>());
     hipLaunchKernelGGL(big_scatter_kernel, dim3(n_chunks), dim3(kBlock), 0, stream, cur->as<Seg>(), n_segs, chunk_off.as<uint32_t>(),
                        dec.as<BigDecision>(), centroid, in, out, chunk_left.as<uint32_t>());
     RTB(hipMemsetAsync(counts.p, 0, 4, stream));  // the next level's list starts empty; the small list keeps growing
     hipLaunchKernelGGL(big_children_kernel, dim3((n_segs + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cur->as<Seg>(), n_segs, dec.as<BigDecision>(),
                        out, buf ^ 1u, nxt->as<Seg>(), small.as<Seg>(), counts.as<uint32_t>(), L);
-    hipLaunchKernelGGL(big_plan_kernel, dim3(1), dim3(1), 0, stream, nxt->as<Seg>(), chunk_off.as<uint32_t>(), counts.as<uint32_t>());
+    hipLaunchKernelGGL(big_plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, nxt->as<Seg>(), chunk_off.as<uint32_t>(), counts.as<uint32_t>());
     RTB(hipGetLastError());
     uint32_t host_counts[4] = {0, 0, 0, 0};
     RTB(hipMemcpyAsync(host_counts, counts.p, 16, hipMemcpyDeviceToHost, stream));
