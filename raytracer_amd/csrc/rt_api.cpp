@@ -126,8 +126,9 @@ std::atomic<bool> g_force_wide{false};
 std::atomic<uint64_t> g_wavefront_paths{32u << 20};
 #endif
 
-// RT_BUILD_AUTO: scenes of this many spheres or more are built on the device (host build 60 ms and up, device build 5 ms).
-constexpr size_t kAutoDeviceBuild = 65536;
+// RT_BUILD_AUTO: scenes of this many spheres or more get their tree from the device's surface-area build, which makes the host
+// builder's tree (1.8 against 2.4 ms here, 2.4 against 25 ms at 10^4 spheres, 17 against 680 ms at 10^6).
+constexpr size_t kAutoDeviceBuild = 1024;
 
 // Partial sums of an allocating render call never exceed this; the sample range is cut into fewer chunks instead.
 constexpr uint64_t kWorkspaceLimit = 4ull << 30;
@@ -524,7 +525,7 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
                  size_t n_devices, bool current_device_only, rt_scene** out) {
   if (!out) return fail(RT_ERR_INVALID, "rt_scene_create: out is null");
   if (builder > RT_BUILD_DEVICE_SAH) return fail(RT_ERR_INVALID, "rt_scene_create: unknown builder");
-  if (builder == RT_BUILD_AUTO) builder = n >= kAutoDeviceBuild ? RT_BUILD_DEVICE_LBVH : RT_BUILD_HOST_SAH;
+  if (builder == RT_BUILD_AUTO) builder = n >= kAutoDeviceBuild ? RT_BUILD_DEVICE_SAH : RT_BUILD_HOST_SAH;
   *out = nullptr;
   if ((n && !spheres) || (nm && !materials)) return fail(RT_ERR_INVALID, "rt_scene_create: null array");
   if (n >= kMaxSlots) return fail(RT_ERR_LIMIT, "rt_scene_create: at most 16777199 spheres");
