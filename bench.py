@@ -141,7 +141,7 @@ def other_configs(rt, torch):
         else:
             spheres, materials = rt.scene_field(seed, n, pl, pm, fz)
             cfg = rt.config_field(n, width, spp, depth)
-        world = rt.BVH(spheres, materials)
+        world = rt.BVH(spheres, materials, builder=rt.BUILD_AUTO)  # as rt_scene_create does: the reference's tree, built on the device from 1024 spheres on
         cam = cfg.camera()
         frame = torch.zeros((cam.image_height, width, 3), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
@@ -162,7 +162,7 @@ def other_configs(rt, torch):
             "Mrays_per_s": rate / 1e6, "kernel_ms": st["kernel_ms"], "kernel_ms_of_three": [r["kernel_ms"] for r in runs], "rays": st["rays"], "mean_path_length": st["rays"] / float(st["samples"]),
             "node_visits_per_ray": v, "sphere_tests_per_ray": p, "flops_per_ray": flops_per_ray(v, p),
             "frac": rate * flops_per_ray(v, p) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
-            "build_ms": info["build_ms"], "walk": "two-wide tree in LDS" if info["n_nodes_in_lds"] == info["n_device_nodes"] else "four-wide tree, top in LDS",
+            "build_ms": info["build_ms"], "builder": {0: "host", 1: "device, clustering", 3: "device, the reference's surface-area splits"}.get(int(info["builder"]), "?"), "walk": "two-wide tree in LDS" if info["n_nodes_in_lds"] == info["n_device_nodes"] else "four-wide tree, top in LDS",
             "frame_mean_radiance": float(frame.mean().item()) / spp,
         })
         world.close()

@@ -151,19 +151,22 @@ void rt_config_default(rt_config* cfg);
 int rt_camera_derive(const rt_config* cfg, rt_camera* out);
 
 /* `BVH::new(objects)` (src/bvh.rs:44-48, builder :92-266 without the unfinished
- * spatial splits): copies the inputs, builds the tree (RT_BUILD_AUTO below: the reference's
- * binned-SAH tree on the host for scenes below 65 536 spheres, the device builder
- * above), flattens it and uploads it to the current HIP device. */
+ * spatial splits): copies the inputs, builds the reference's binned-SAH tree (RT_BUILD_AUTO below: on the
+ * host for scenes below 1 024 spheres, on the device above), flattens it and uploads it to the current
+ * HIP device. */
 int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_material* materials, size_t n_materials, rt_scene** out);
 
-/* rt_scene_create with a choice of tree builder.  RT_BUILD_HOST_SAH is the
- * reference's binned-SAH tree, built by host threads (0.1 s for 10^5 spheres, 0.65 s for
- * 10^6 on 16 cores).  RT_BUILD_DEVICE_LBVH builds on the GPU in milliseconds (6 and 20 ms):
- * the spheres in Morton order, clustered bottom-up.  A different tree over the same spheres,
- * so closest hits are the same (exact ties between overlapping spheres aside) while a render
- * takes 4 - 8 % longer.  RT_BUILD_AUTO takes the host builder below 65 536 spheres and the
- * device builder from there on, where the host build costs more than it saves in a render of
- * up to a few seconds. */
+/* rt_scene_create with a choice of tree builder.  RT_BUILD_HOST_SAH is the reference's
+ * binned-SAH tree, built by host threads (0.1 s for 10^5 spheres, 0.65 s for 10^6 on 16 cores).
+ * RT_BUILD_DEVICE_SAH is the same algorithm on the GPU (5 ms and 17 ms): the same boxes, buckets,
+ * costs and partitions, so the same tree node for node and the same render; where the reference
+ * would keep several spheres in one leaf (spheres on top of each other: no split cheaper than
+ * the leaf) it cuts the leaf in the middle until every leaf holds one sphere.
+ * RT_BUILD_DEVICE_LBVH clusters the spheres bottom-up along their Morton order (19 ms for 10^6):
+ * a different tree over the same spheres, so closest hits are the same (exact ties between
+ * overlapping spheres aside) while a render takes 4 - 9 % longer.  RT_BUILD_AUTO takes the host
+ * builder below 1 024 spheres and RT_BUILD_DEVICE_SAH from there on.  A scene built on the
+ * device keeps no host tree: rt_scene_bvh_dump refuses it. */
 enum { RT_BUILD_HOST_SAH = 0, RT_BUILD_DEVICE_LBVH = 1, RT_BUILD_AUTO = 2, RT_BUILD_DEVICE_SAH = 3 };
 int rt_scene_create_ex(const rt_sphere* spheres, size_t n_spheres, const rt_material* materials, size_t n_materials, uint32_t builder,
                        rt_scene** out);

@@ -8,6 +8,7 @@ pub const RT_DIELECTRIC: u32 = 2;
 pub const RT_BUILD_HOST_SAH: u32 = 0;
 pub const RT_BUILD_DEVICE_LBVH: u32 = 1;
 pub const RT_BUILD_AUTO: u32 = 2;
+pub const RT_BUILD_DEVICE_SAH: u32 = 3;
 pub const RT_PARTITION_TILES: u32 = 0;
 pub const RT_PARTITION_SAMPLES: u32 = 1;
 

@@ -12,5 +12,5 @@ g++ $HOST -DRTA_EXPERIMENTS "$@" -c rt_api.cpp -o /tmp/rt_api_$NAME.o
 /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -I../../include -I. -Wall -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c rt_kernels.hip -o /tmp/rt_kernels_$NAME.o
 /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -I../../include -I. -Wall -fno-slp-vectorize "$@" -c rt_wavefront.hip -o /tmp/rt_wavefront_$NAME.o
 /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -I../../include -I. -Wall -fno-slp-vectorize "$@" -c rt_cuts.hip -o /tmp/rt_cuts_$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/raytracer_amd/variants/lib$NAME.so" /tmp/bvh_builder_$NAME.o rt_host.o /tmp/rt_api_$NAME.o /tmp/rt_kernels_$NAME.o /tmp/rt_wavefront_$NAME.o /tmp/rt_cuts_$NAME.o rt_build.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/raytracer_amd/variants/lib$NAME.so" /tmp/bvh_builder_$NAME.o rt_host.o /tmp/rt_api_$NAME.o /tmp/rt_kernels_$NAME.o /tmp/rt_wavefront_$NAME.o /tmp/rt_cuts_$NAME.o rt_build.o rt_build_sah.o
 echo built "$R/raytracer_amd/variants/lib$NAME.so"

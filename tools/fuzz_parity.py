@@ -92,7 +92,7 @@ def main():
     t_start = time.time()
     for case in range(a.cases):
         spheres, materials = random_scene(rng)
-        builder = rt.BUILD_DEVICE_LBVH if rng.random() < 0.4 else rt.BUILD_HOST_SAH
+        builder = (rt.BUILD_HOST_SAH, rt.BUILD_DEVICE_LBVH, rt.BUILD_DEVICE_SAH)[int(rng.integers(0, 3))]
         world = rt.BVH(spheres, materials, builder=builder)
         oworld = orc.Scene(spheres.view(orc.SPHERE_DTYPE), materials.view(orc.MATERIAL_DTYPE))
         cfg = random_config(rng, spheres)
@@ -137,7 +137,7 @@ def main():
         n_off = int((diff > 1e-6 * scale).sum())
         rays_ok = abs(st["rays"] - int(ost[0])) <= n_off * 7 + 0.002 * int(ost[0])
         line = ("case %3d: %5d spheres %s tree, %3dx%-3d spp [%d,%d) depth %3d tile %s: near-ties %d, pixels equal %.4f, rays %d / %d"
-                % (case, len(spheres), "lbvh" if builder == rt.BUILD_DEVICE_LBVH else "sah ", w, h, s0, s1, depth, tile, ties, frac, st["rays"], int(ost[0])))
+                % (case, len(spheres), {rt.BUILD_HOST_SAH: "sah ", rt.BUILD_DEVICE_LBVH: "lbvh", rt.BUILD_DEVICE_SAH: "dsah"}[builder], w, h, s0, s1, depth, tile, ties, frac, st["rays"], int(ost[0])))
         line += " [worst relative difference %.1e, %d pixels beyond 1e-6]" % ((diff / scale).max(), n_off)
         assert np.isfinite(got).all()
         assert n_off <= 0.03 * diff.size + 1 and rays_ok, line

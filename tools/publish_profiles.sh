@@ -11,5 +11,6 @@ cp $R/pmc_summary_reduce_chunks.json profiles/${N}_pmc_summary_reduce_chunks.jso
 cp $R/stress_host.jsonl profiles/${N}_stress_configs_full_spp.jsonl
 cp $R/stress_host.jsonl profiles/${N}_config_rooflines.jsonl
 cp $R/stress_device.jsonl profiles/${N}_stress_configs_device_lbvh_full_spp.jsonl
+cp $R/stress_device_sah.jsonl profiles/${N}_stress_configs_device_sah_full_spp.jsonl
 python3 tools/make_hbm_traffic.py $R > profiles/${N}_hbm_traffic.json
 echo published

@@ -12,6 +12,7 @@ step timeout -k 10 300 python3 bench.py > "$OUT/bench_line.json" 2> "$OUT/bench_
 RT_PROFILE_BLOCKS=1 timeout -k 10 120 python3 tools/perf_sweep.py inner_min 10 --spp 200 --rounds 1 > "$OUT/block_profile.txt" 2>&1 || exit 1
 step timeout -k 10 300 python3 tools/run_configs.py --only c1,c2,c5,c3,c4 --rooflines > "$OUT/stress_host.jsonl" 2> "$OUT/stress_host.err"
 step timeout -k 10 300 python3 tools/run_configs.py --only c5,c3,c4 --builder device > "$OUT/stress_device.jsonl" 2> "$OUT/stress_device.err"
+step timeout -k 10 300 python3 tools/run_configs.py --only c5,c3,c4 --builder device-sah > "$OUT/stress_device_sah.jsonl" 2> "$OUT/stress_device_sah.err"
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --no-cpu-baseline --no-other-configs > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err" || { tail -5 "$OUT/stats.err"; exit 1; }
 cd "$R"

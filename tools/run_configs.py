@@ -27,7 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="c1,c3,c4,c5")
     ap.add_argument("--scale", type=float, default=1.0)
-    ap.add_argument("--builder", choices=["host", "device"], default="host")
+    ap.add_argument("--builder", choices=["host", "device", "device-sah"], default="host")  # device: the clustering builder
     ap.add_argument("--rooflines", action="store_true",
                     help="also run the CPU oracle on a 160-pixel-wide, 2-spp sample of each configuration for the reference's node visits and sphere "
                          "tests per ray, and price the measured ray rate against the vector-ALU and HBM ceilings")
@@ -36,9 +36,10 @@ def main():
 
     import raytracer_amd as rt
 
-    if args.builder == "device":  # the first device build of a process pays one-time set-up (code object load, sort temporaries)
+    builder = {"host": rt.BUILD_HOST_SAH, "device": rt.BUILD_DEVICE_LBVH, "device-sah": rt.BUILD_DEVICE_SAH}[args.builder]
+    if args.builder != "host":  # the first device build of a process pays one-time set-up (code object load, sort temporaries)
         ws, wm = rt.scene_field(1, 1000, 1 / 3, 1 / 3, 1.0)
-        rt.BVH(ws, wm, builder=rt.BUILD_DEVICE_LBVH).close()
+        rt.BVH(ws, wm, builder=builder).close()
     for name in args.only.split(","):
         n, pl, pm, fz, width, spp, depth, seed = CONFIGS[name]
         spp = max(1, int(spp * args.scale))
@@ -50,7 +51,7 @@ def main():
             spheres, materials = rt.scene_field(seed, n, pl, pm, fz)
             cfg = rt.config_field(n, width, spp, depth)
         t1 = time.perf_counter()
-        world = rt.BVH(spheres, materials, builder=rt.BUILD_DEVICE_LBVH if args.builder == "device" else rt.BUILD_HOST_SAH)
+        world = rt.BVH(spheres, materials, builder=builder)
         t2 = time.perf_counter()
         cam = cfg.camera()
         frame = torch.zeros((cam.image_height, width, 3), dtype=torch.float64, device="cuda")
