@@ -167,7 +167,8 @@ class BVH:
     """`BVH::new(objects)` (src/bvh.rs:44-48) on the current HIP device.
 
     `objects` is a list of Sphere, or a pair (sphere records, material records).  builder: BUILD_HOST_SAH (the
-    reference's tree), BUILD_DEVICE_LBVH (built on the GPU; same hits, a different tree) or BUILD_AUTO (the host tree below 65 536 spheres).  devices: None for one
+    reference's tree, built on the host), BUILD_DEVICE_SAH (the same tree built on the GPU), BUILD_DEVICE_LBVH (built on the GPU by clustering; same hits,
+    a different tree) or BUILD_AUTO (the host below 1 024 spheres, BUILD_DEVICE_SAH above: what rt_scene_create does).  devices: None for one
     copy on the current device; "all" or a list of HIP ordinals for a copy on each (Camera.render and
     Camera.render_multi then use all of them)."""
 
