@@ -380,7 +380,7 @@ def main():
                 "name": "c2", "workload": "488 spheres, %dx%d, %d spp, max depth %d (the timed headline above)" % (w, h, args.spp, args.depth),
                 "Mrays_per_s": rays_per_launch / (k_ms * 1e-3) / 1e6, "kernel_ms": k_ms, "rays": rays_per_launch,
                 "mean_path_length": out["config"]["mean_path_length"], "node_visits_per_ray": v_bar, "sphere_tests_per_ray": p_bar,
-                "flops_per_ray": flops_per_ray(v_bar, p_bar), "frac": out["roofline"]["frac"], "build_ms": world.info()["build_ms"],
+                "flops_per_ray": flops_per_ray(v_bar, p_bar), "frac": out["roofline"]["frac"], "build_ms": world.info()["build_ms"], "builder": "host",
                 "walk": "two-wide tree in LDS", "frame_mean_radiance": out["config"]["frame_mean_radiance"],
             }
             out["configs"] = [head] + other_configs(rt, torch)

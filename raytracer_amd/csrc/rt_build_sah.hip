@@ -27,12 +27,16 @@ constexpr uint32_t kSmall = 128;          // segments up to this size are finish
 constexpr uint32_t kChunk = 2048;         // positions of a large segment that one block works on
 constexpr int kBlock = 256;
 constexpr uint32_t kNone = 0xffffffffu, kLeafBit = 0x80000000u;
+// Below this level the host builder stops splitting (bvh_builder.cpp: inputs such as spheres in geometric progression would
+// otherwise cost a level per sphere); here the segments are cut in the middle from there on, so the tree stays below 64 + log2(n) levels.
+constexpr uint32_t kMaxBuildDepth = 64;
 
 struct Seg {
   uint32_t lo, hi;  // positions [lo, hi) of the index array
   uint32_t parent;  // id of the parent node, kNone for the root
-  uint32_t side;    // bit 0: 0 = the parent's child 0, 1 = its child 1; bit 1 (segments handed to the small kernel): which index array holds the segment
+  uint32_t side;    // bit 0: 0 = the parent's child 0, 1 = its child 1; bit 1 (segments handed to the small kernel): which index array holds the segment; bits 8 and up: the node's level (root: 1)
 };
+__device__ __forceinline__ uint32_t level_of(const Seg& s) { return s.side >> 8; }
 
 // Doubles as integers that compare the same way (finite values, infinities and zeros of either sign).
 __device__ __forceinline__ unsigned long long okey(double v) {
@@ -96,7 +100,7 @@ __device__ __forceinline__ void lane_sync() { __syncthreads(); }  // (blocks of 
 // The split of a segment of n spheres, by the 64 lanes of a wave together (every lane returns the same answer).
 // The sweep of src/bvh.rs:196-227: per axis whose centroids differ, every boundary between buckets, cost
 // kSplitCost + kLeafCost * (n_left * area_left + n_right * area_right) / area_node, the lowest by total order, the first of equals.
-__device__ __forceinline__ Decision pick_split(const Hist* h, const Bounds& b, uint32_t n, Sweep* sw, uint32_t lane) {
+__device__ __forceinline__ Decision pick_split(const Hist* h, const Bounds& b, uint32_t n, bool may_split, Sweep* sw, uint32_t lane) {
   bool valid[3];
   for (int a = 0; a < 3; ++a) valid[a] = (b.cmax[a] - b.cmin[a]) > 0.0;
   if (lane < 6) {
@@ -163,7 +167,7 @@ __device__ __forceinline__ Decision pick_split(const Hist* h, const Bounds& b, u
   d.nl = n / 2;
   if (best_c != (1 << 30)) {
     const double best_cost = cost_of(best_c);
-    if (best_cost < kLeafCost * (double)n) {  // src/bvh.rs:124
+    if (best_cost < kLeafCost * (double)n && may_split) {  // src/bvh.rs:124
       d.sah = true;
       d.axis = best_c / (kBuckets - 1);
       d.split = best_c % (kBuckets - 1) + 1;
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(64) void small_kernel(const Seg* __restrict__ roots
         if (d.sah) {
           const Box6 &first = swap ? b1 : b0, &second = swap ? b0 : b1;
           const double cost = kSplitCost + kLeafCost * ((double)1u * surface_area(first.lo, first.hi) + (double)1u * surface_area(second.lo, second.hi)) / surface_area(lo, hi);
-          if (!(cost < kLeafCost * (double)2u)) d.sah = swap = false;  // src/bvh.rs:124: the reference keeps the two in one leaf; here they stay as they are
+          if (!(cost < kLeafCost * (double)2u) || level_of(s) >= kMaxBuildDepth) d.sah = swap = false;  // src/bvh.rs:124: the reference keeps the two in one leaf; here they stay as they are
         }
         const uint32_t id = make_node(L, s, d, lo, hi);
         L.left[id] = kLeafBit | s.lo;
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(64) void small_kernel(const Seg* __restrict__ roots
         if ((b.cmax[a] - b.cmin[a]) > 0.0) hist_add(&h, a, choose_bucket(b.cmin[a], b.cmax[a], centroid[3 * (size_t)prim + a]), box);
     }
     lane_sync();
-    const Decision d = pick_split(&h, b, n, &sw, lane);
+    const Decision d = pick_split(&h, b, n, level_of(s) < kMaxBuildDepth, &sw, lane);
     const uint32_t mid = s.lo + d.nl;
     const bool leaf_left = d.nl == 1u, leaf_right = s.hi - mid == 1u;
     uint32_t newbuf = buf;
@@ -360,11 +364,11 @@ __global__ __launch_bounds__(64) void small_kernel(const Seg* __restrict__ roots
       if (leaf_right)
         make_leaf(L, id, 1u, mid);
       else
-        stack[sp] = Seg{mid, s.hi, id, 1u | (newbuf << 1)};
+        stack[sp] = Seg{mid, s.hi, id, 1u | (newbuf << 1) | ((level_of(s) + 1u) << 8)};
       if (leaf_left)
         make_leaf(L, id, 0u, s.lo);
       else
-        stack[sp + (leaf_right ? 0 : 1)] = Seg{s.lo, mid, id, 0u | (newbuf << 1)};
+        stack[sp + (leaf_right ? 0 : 1)] = Seg{s.lo, mid, id, 0u | (newbuf << 1) | ((level_of(s) + 1u) << 8)};
     }
     sp += (leaf_right ? 0 : 1) + (leaf_left ? 0 : 1);
     lane_sync();
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(64) void big_decide_kernel(const Seg* __restrict__ 
   if (k >= n_segs) return;
   const Seg s = segs[k];
   const Bounds b = bounds_of(acc[k]);
-  const Decision d = pick_split(&acc[k].h, b, s.hi - s.lo, &sw, threadIdx.x);
+  const Decision d = pick_split(&acc[k].h, b, s.hi - s.lo, level_of(s) < kMaxBuildDepth, &sw, threadIdx.x);
   if (threadIdx.x == 0) {
     BigDecision out;
     out.d = d;
@@ -592,9 +596,9 @@ __global__ __launch_bounds__(kBlock) void big_children_kernel(const Seg* __restr
       L.order[lo] = arr[lo];
     }
     else if (hi - lo <= kSmall)
-      small[atomicAdd(&counts[1], 1u)] = Seg{lo, hi, bd.id, side | (buf << 1)};
+      small[atomicAdd(&counts[1], 1u)] = Seg{lo, hi, bd.id, side | (buf << 1) | ((level_of(s) + 1u) << 8)};
     else
-      next[atomicAdd(&counts[0], 1u)] = Seg{lo, hi, bd.id, side};
+      next[atomicAdd(&counts[0], 1u)] = Seg{lo, hi, bd.id, side | ((level_of(s) + 1u) << 8)};
   }
 }
 
@@ -670,7 +674,7 @@ hipError_t sah_hierarchy(const Box6* prim_box, const double* centroid, uint32_t 
   hipLaunchKernelGGL(iota_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, idx0.as<uint32_t>(), n);  // ascending sphere order, as on the host
   const Links L{left, right, parent_inner, parent_leaf, order, root_id, axis, node_box};
 
-  const Seg root{0u, n, kNone, 0u};
+  const Seg root{0u, n, kNone, 1u << 8};
   uint32_t n_segs = 0, n_chunks = 0, n_small = 0;
   Scratch *cur = &segs_a, *nxt = &segs_b;
   if (n <= kSmall) {
@@ -685,7 +689,7 @@ hipError_t sah_hierarchy(const Box6* prim_box, const double* centroid, uint32_t 
   }
   uint32_t buf = 0;  // the index array the level's segments are in
   for (uint32_t level = 0; n_segs > 0; ++level) {
-    if (level > 4096 || n_segs > max_big || n_chunks > max_chunks) return hipErrorUnknown;  // cannot happen; never run past the buffers
+    if (level > kMaxBuildDepth + 40 || n_segs > max_big || n_chunks > max_chunks) return hipErrorUnknown;  // cannot happen; never run past the buffers
     const uint32_t* in = buf ? idx1.as<uint32_t>() : idx0.as<uint32_t>();
     uint32_t* out = buf ? idx0.as<uint32_t>() : idx1.as<uint32_t>();
     hipLaunchKernelGGL(big_clear_kernel, dim3(n_segs), dim3(kBlock), 0, stream, acc.as<BigAcc>(), n_segs);

@@ -590,11 +590,17 @@ def test_device_built_tree_large_and_degenerate(builder):
     piles["center"] = np.repeat(rng.uniform(-8.0, 8.0, size=(30, 3)) + np.array([0.0, 0.0, 5.0]), 30, axis=0)
     piles["radius"] = 0.4
     cases["piles"] = piles
+    prog = np.zeros(180, dtype=rt.SPHERE_DTYPE)  # centres in geometric progression: the cheapest split peels one sphere off, level after level, beyond the builders' depth limit
+    prog["center"][:, 0] = 1.2 ** np.arange(180)
+    prog["center"][:, 2] = 5.0
+    prog["radius"] = 0.05 * prog["center"][:, 0]
+    cases["progression"] = prog
     for name, sp in cases.items():
         w = rt.BVH(sp, mat, builder=builder)
-        aim = sp["center"][rng.integers(0, len(sp), 512)]
-        org = aim + rng.normal(size=(512, 3)) * 3.0 + np.array([0.0, 0.0, -8.0])
-        d = aim + rng.normal(size=(512, 3)) * 0.2 - org
+        pick = rng.integers(0, len(sp), 512)
+        aim, size = sp["center"][pick], np.maximum(1.0, sp["radius"][pick, None] / 0.3)
+        org = aim + (rng.normal(size=(512, 3)) * 3.0 + np.array([0.0, 0.0, -8.0])) * size
+        d = aim + rng.normal(size=(512, 3)) * 0.2 * size - org
         got = w.trace_batch(org, d)
         prim, t = _brute_force_hits(sp, org, d)
         hit = prim >= 0
