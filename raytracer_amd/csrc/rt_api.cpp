@@ -514,7 +514,6 @@ int make_replica(Replica& rp, const rt_sphere* spheres, size_t n, size_t nm, siz
   dev.single_leaves = single ? 1u : 0u;
   dev.first_leaf = wide && !wide_peel ? kRefNone : first_leaf;
   if (!wide && first_leaf != kRefNone) dev.root = walk_root;
-  if (n > 0) RT_HIP(preload_render(dev));
   *on_device_out = on_device;
   *depth_out = on_device ? tree.depth : tree_depth;
   *n_dev_nodes_out = n_final_nodes;
@@ -685,6 +684,9 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
       break;
     }
     if (k == 0) build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    // (not part of the build time: a process pays it once per kernel variant) the render kernel's code is loaded now, so that
+    // the first frame costs what the later ones do
+    if (n > 0) RT_HIP(preload_render(rp->dev));
     sc->reps.push_back(std::move(rp));
   }
 
