@@ -595,35 +595,47 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
     }
     return k;
   };
-  // (an open-addressing table over the records met so far: a node-based map spent 80 ms here on a scene of 10^6 materials)
+  // (an open-addressing table over the records met so far: a node-based map spent 80 ms here on a scene of 10^6 materials.
+  // Beyond 65 536 materials nothing is looked for: a table that size is far from fitting in LDS whatever it shares, and the
+  // search itself, 45 ms at 10^6, would be most of what scene creation costs; the table is then the caller's, in its order.)
+  const bool dedup = nm <= 65536;
   std::vector<const rt_material*> table;
-  std::vector<Key> table_key;
-  size_t n_slots = 64;
-  int slot_bits = 6;
-  while (n_slots < 2 * nm) n_slots *= 2, ++slot_bits;
-  std::vector<uint32_t> slot(n_slots, 0u);  // 0: free, else a table index + 1
-  table.reserve(nm);
-  table_key.reserve(nm);
-  sc->table_index.assign(nm, 0xffffffffu);
-  auto place = [&](size_t m) {
-    if (sc->table_index[m] != 0xffffffffu) return;
-    const Key k = key_of(materials[m]);
-    size_t h = (size_t)(((uint64_t)KeyHash{}(k) * 0x9E3779B97F4A7C15ull) >> (64 - slot_bits));  // the top bits: the best mixed
-    while (slot[h] && !(table_key[slot[h] - 1u] == k)) h = (h + 1) & (n_slots - 1);
-    if (!slot[h]) {
-      slot[h] = (uint32_t)table.size() + 1u;
-      table.push_back(&materials[m]);
-      table_key.push_back(k);
+  std::vector<rt_sphere> placed;  // the spheres with their materials' table indices
+  size_t n_used = nm;
+  if (dedup) {
+    std::vector<Key> table_key;
+    size_t n_slots = 64;
+    int slot_bits = 6;
+    while (n_slots < 2 * nm) n_slots *= 2, ++slot_bits;
+    std::vector<uint32_t> slot(n_slots, 0u);  // 0: free, else a table index + 1
+    table.reserve(nm);
+    table_key.reserve(nm);
+    sc->table_index.assign(nm, 0xffffffffu);
+    auto place = [&](size_t m) {
+      if (sc->table_index[m] != 0xffffffffu) return;
+      const Key k = key_of(materials[m]);
+      size_t h = (size_t)(((uint64_t)KeyHash{}(k) * 0x9E3779B97F4A7C15ull) >> (64 - slot_bits));  // the top bits: the best mixed
+      while (slot[h] && !(table_key[slot[h] - 1u] == k)) h = (h + 1) & (n_slots - 1);
+      if (!slot[h]) {
+        slot[h] = (uint32_t)table.size() + 1u;
+        table.push_back(&materials[m]);
+        table_key.push_back(k);
+      }
+      sc->table_index[m] = slot[h] - 1u;
+    };
+    placed.assign(spheres, spheres + n);
+    for (size_t i = 0; i < n; ++i) {
+      place(spheres[i].material);
+      placed[i].material = sc->table_index[spheres[i].material];
     }
-    sc->table_index[m] = slot[h] - 1u;
-  };
-  std::vector<rt_sphere> placed(spheres, spheres + n);  // the spheres with their materials' table indices
-  for (size_t i = 0; i < n; ++i) {
-    place(spheres[i].material);
-    placed[i].material = sc->table_index[spheres[i].material];
+    n_used = table.size();
+    for (size_t m = 0; m < nm; ++m) place(m);  // materials no sphere uses: kept for rt_scatter_batch, never staged
+    spheres = placed.data();
+  } else {
+    table.resize(nm);
+    sc->table_index.resize(nm);
+    for (size_t m = 0; m < nm; ++m) table[m] = &materials[m], sc->table_index[m] = (uint32_t)m;
   }
-  const size_t n_used = table.size();
-  for (size_t m = 0; m < nm; ++m) place(m);  // materials no sphere uses: kept for rt_scatter_batch, never staged
   const size_t n_table = table.size();
 
   // Table records, 32 bytes each (layout documented at scatter() in rt_device.h); the type
@@ -646,7 +658,6 @@ int create_scene(const rt_sphere* spheres, size_t n, const rt_material* material
       d[3] = m.type == RT_METAL ? m.param : 0.0;
     }
   }
-  spheres = placed.data();
 
   // The tree: built on the host with the reference's algorithm (once, then uploaded to every device), or on each
   // device (two or more spheres; a tree too deep for the traversal stack falls back to the host builder).
