@@ -183,6 +183,9 @@ int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
  * Used to compare the builder with the reference's algorithm node by node. */
 typedef struct rt_host_bvh rt_host_bvh;
 int rt_bvh_build(const rt_sphere* spheres, size_t n_spheres, rt_host_bvh** out);
+/* The same tree from the device's builder (RT_BUILD_DEVICE_SAH, on the current HIP device), brought back in the same form:
+ * `BVH::new` (src/bvh.rs:92-266) computed on the GPU, for comparing it with the reference's algorithm node by node. */
+int rt_bvh_build_device(const rt_sphere* spheres, size_t n_spheres, rt_host_bvh** out);
 int rt_bvh_destroy(rt_host_bvh* bvh);
 int rt_bvh_counts(const rt_host_bvh* bvh, uint64_t* n_nodes, uint64_t* n_leaf_indices, uint32_t* depth);
 /* Same layout as rt_scene_bvh_dump. */

@@ -88,6 +88,7 @@ EXPORTS = [
     "rt_scene_destroy",
     "rt_scene_get_info",
     "rt_bvh_build",
+    "rt_bvh_build_device",
     "rt_bvh_destroy",
     "rt_bvh_counts",
     "rt_bvh_dump",

@@ -428,12 +428,13 @@ def slab_batch(boxes, org, direction, interval):
     return hit.astype(bool)
 
 
-def host_bvh(spheres):
-    """Host-only build: returns (boxes, kind, skip_or_count, leaf_indices, depth)."""
+def host_bvh(spheres, on_device=False):
+    """The tree alone, in the reference's layout: returns (boxes, kind, skip_or_count, leaf_indices, depth).  on_device: built by the
+    GPU's builder and brought back (needs a GPU) instead of by the host's."""
     spheres = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
     h = C.c_void_p()
     L = _lib.lib()
-    check(L.rt_bvh_build(ptr(spheres), C.c_size_t(len(spheres)), C.byref(h)))
+    check((L.rt_bvh_build_device if on_device else L.rt_bvh_build)(ptr(spheres), C.c_size_t(len(spheres)), C.byref(h)))
     try:
         nn, nl, depth = C.c_uint64(), C.c_uint64(), C.c_uint32()
         check(L.rt_bvh_counts(h, C.byref(nn), C.byref(nl), C.byref(depth)))

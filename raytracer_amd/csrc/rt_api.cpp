@@ -1231,6 +1231,69 @@ int rt_bvh_build(const rt_sphere* spheres, size_t n, rt_host_bvh** out) {
     return RT_OK;
   });
 }
+// The device-built hierarchy in the reference's layout: nodes in pre-order, a split's second child `skip` nodes on, leaves
+// with their spheres; where the device build cut a would-be leaf of the reference in the middle, the leaf is put together again.
+int rt_bvh_build_device(const rt_sphere* spheres, size_t n, rt_host_bvh** out) {
+  return guarded("rt_bvh_build_device", [&]() -> int {
+    if (!out || (n && !spheres)) return fail(RT_ERR_INVALID, "rt_bvh_build_device: null argument");
+    if (n >= kMaxSlots) return fail(RT_ERR_LIMIT, "rt_bvh_build_device: at most 16777199 spheres");
+    std::unique_ptr<rt_host_bvh> b(new rt_host_bvh());
+    if (n < 2) {  // nothing to split
+      b->bvh = build_bvh(spheres, n);
+      *out = b.release();
+      return RT_OK;
+    }
+    HostHierarchy h;
+    RT_HIP(device_build_hierarchy(spheres, n, &h, nullptr));
+    HostBvh& t = b->bvh;
+    t.nodes.reserve(2 * n);
+    t.leaf_indices.reserve(n);
+    auto sphere_box = [&](uint32_t i) {  // Sphere::aabb, src/sphere.rs:50-52, as build_bvh computes it
+      Box bx;
+      for (int a = 0; a < 3; ++a) {
+        const double p0 = spheres[i].center[a] - spheres[i].radius, p1 = spheres[i].center[a] + spheres[i].radius;
+        bx.min[a] = std::fmin(p0, p1);
+        bx.max[a] = std::fmax(p0, p1);
+      }
+      return bx;
+    };
+    auto node_box = [&](uint32_t id) {
+      Box bx;
+      for (int a = 0; a < 3; ++a) bx.min[a] = h.boxes[6 * (size_t)id + a], bx.max[a] = h.boxes[6 * (size_t)id + 3 + a];
+      return bx;
+    };
+    constexpr uint32_t kLeaf = 0x80000000u;
+    std::function<void(uint32_t)> gather = [&](uint32_t ref) {  // the spheres below ref, left to right
+      if (ref & kLeaf) {
+        t.leaf_indices.push_back(h.order[ref & ~kLeaf]);
+        return;
+      }
+      gather(h.left[ref]);
+      gather(h.right[ref]);
+    };
+    std::function<void(uint32_t, uint32_t)> emit = [&](uint32_t ref, uint32_t level) {
+      t.depth = std::max(t.depth, level);
+      if (ref & kLeaf) {
+        const uint32_t prim = h.order[ref & ~kLeaf];
+        t.nodes.push_back(HostNode{sphere_box(prim), 3, 0, t.leaf_indices.size(), 1});
+        t.leaf_indices.push_back(prim);
+      } else if (h.axis[ref] > 2) {
+        const uint64_t first = t.leaf_indices.size();
+        gather(ref);
+        t.nodes.push_back(HostNode{node_box(ref), 3, 0, first, t.leaf_indices.size() - first});
+      } else {
+        const size_t me = t.nodes.size();
+        t.nodes.push_back(HostNode{node_box(ref), (int32_t)h.axis[ref], 0, 0, 0});
+        emit(h.left[ref], level + 1);
+        t.nodes[me].skip = t.nodes.size() - me;  // src/bvh.rs:126-130
+        emit(h.right[ref], level + 1);
+      }
+    };
+    emit(h.root, 1);
+    *out = b.release();
+    return RT_OK;
+  });
+}
 int rt_bvh_destroy(rt_host_bvh* b) {
   delete b;
   return RT_OK;

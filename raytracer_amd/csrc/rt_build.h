@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "rt.h"
 
 namespace rta {
@@ -30,6 +32,18 @@ enum class DeviceBuilder { kClustering, kBinnedSah };
 // Returns when the tree is complete.
 hipError_t device_build(const rt_sphere* spheres, size_t n, const uint8_t* material_type, size_t n_materials, DeviceBuilder builder,
                         DeviceTree* out, hipStream_t stream);
+
+// The hierarchy the device's surface-area build makes, brought back to the host so that it can be compared with the
+// reference's tree: n - 1 nodes and n leaves.  left/right[id]: a child -- a node's id, or 0x80000000 | k for leaf k, which
+// holds sphere order[k]; boxes: 6 doubles per node (low xyz, high xyz); axis[id]: 0..2, or 3 where the reference's builder
+// stops and makes one leaf of the node's spheres (src/bvh.rs:124) while the device build goes on cutting in the middle.
+struct HostHierarchy {
+  std::vector<uint32_t> left, right, order;
+  std::vector<uint8_t> axis;
+  std::vector<double> boxes;
+  uint32_t root = 0;
+};
+hipError_t device_build_hierarchy(const rt_sphere* spheres, size_t n, HostHierarchy* out, hipStream_t stream);
 
 // The four-wide tree (WideNode records, bvh_builder.h) collapsed on the device from n_two_wide two-wide nodes in
 // device memory (root = node 0), by the algorithm of collapse_wide on the host, breadth-first.  *d_wide_out is

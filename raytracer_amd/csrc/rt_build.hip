@@ -506,6 +506,46 @@ hipError_t device_collapse_wide(const void* d_two_wide_nodes, uint32_t n_two_wid
   return hipSuccess;
 }
 
+hipError_t device_build_hierarchy(const rt_sphere* h_spheres, size_t n_, HostHierarchy* out, hipStream_t stream) {
+  const uint32_t n = (uint32_t)n_;
+  if (n < 2) return hipErrorInvalidValue;
+  const uint32_t n_inner = n - 1;
+  const unsigned blocks = (n + kThreads - 1) / kThreads;
+  Scratch d_in, prim_box, centroid, block_bounds, left, right, parent_inner, parent_leaf, node_box, axis, order, root;
+  RTB(d_in.alloc((size_t)n * sizeof(rt_sphere)));
+  RTB(hipMemcpyAsync(d_in.p, h_spheres, (size_t)n * sizeof(rt_sphere), hipMemcpyHostToDevice, stream));
+  RTB(prim_box.alloc((size_t)n * sizeof(Box6)));
+  RTB(centroid.alloc((size_t)n * 24));
+  RTB(block_bounds.alloc((size_t)blocks * 48));
+  RTB(left.alloc((size_t)n_inner * 4));
+  RTB(right.alloc((size_t)n_inner * 4));
+  RTB(parent_inner.alloc((size_t)n_inner * 4));
+  RTB(parent_leaf.alloc((size_t)n * 4));
+  RTB(node_box.alloc((size_t)n_inner * sizeof(Box6)));
+  RTB(axis.alloc(n_inner));
+  RTB(order.alloc((size_t)n * 4));
+  RTB(root.alloc(4));
+  hipLaunchKernelGGL(boxes_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, prim_box.as<Box6>(), centroid.as<double>(),
+                     (const uint8_t*)nullptr, block_bounds.as<double>());
+  RTB(hipGetLastError());
+  RTB(sah_hierarchy(prim_box.as<Box6>(), centroid.as<double>(), n, left.as<uint32_t>(), right.as<uint32_t>(), parent_inner.as<uint32_t>(),
+                    parent_leaf.as<uint32_t>(), axis.as<uint8_t>(), node_box.as<Box6>(), order.as<uint32_t>(), root.as<uint32_t>(), stream));
+  out->left.resize(n_inner);
+  out->right.resize(n_inner);
+  out->axis.resize(n_inner);
+  out->boxes.resize((size_t)n_inner * 6);
+  out->order.resize(n);
+  static_assert(sizeof(Box6) == 48, "six doubles");
+  RTB(hipMemcpyAsync(out->left.data(), left.p, (size_t)n_inner * 4, hipMemcpyDeviceToHost, stream));
+  RTB(hipMemcpyAsync(out->right.data(), right.p, (size_t)n_inner * 4, hipMemcpyDeviceToHost, stream));
+  RTB(hipMemcpyAsync(out->axis.data(), axis.p, n_inner, hipMemcpyDeviceToHost, stream));
+  RTB(hipMemcpyAsync(out->boxes.data(), node_box.p, (size_t)n_inner * 48, hipMemcpyDeviceToHost, stream));
+  RTB(hipMemcpyAsync(out->order.data(), order.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+  RTB(hipMemcpyAsync(&out->root, root.p, 4, hipMemcpyDeviceToHost, stream));
+  RTB(hipStreamSynchronize(stream));
+  return out->root < n_inner ? hipSuccess : hipErrorUnknown;
+}
+
 hipError_t device_build(const rt_sphere* h_spheres, size_t n_, const uint8_t* h_material_type, size_t n_materials, DeviceBuilder builder,
                         DeviceTree* out, hipStream_t stream) {
   const uint32_t n = (uint32_t)n_;

@@ -70,3 +70,50 @@ def test_a_million_spheres_get_the_host_tree_in_a_fraction_of_the_time(capfd):
     hi, di = _same_tree(spheres, materials, rt.config_field(1000000, 256, 2, 20).camera(), capfd)
     print("10^6 spheres: host build %.0f ms, device build %.1f ms" % (hi["build_ms"], di["build_ms"]))
     assert di["build_ms"] < 0.2 * hi["build_ms"]
+
+
+# ---- and node by node against the oracle's restatement of BVH::new (src/bvh.rs:92-266): boxes, split axes, skip distances,
+# leaves and the order of the spheres in them, bit for bit ----
+def _oracle_tree(oracle, spheres):
+    sp = spheres.copy()
+    sp["material"] = 0
+    return oracle.Scene(sp.view(oracle.SPHERE_DTYPE), np.zeros(1, dtype=oracle.MATERIAL_DTYPE)).bvh_dump()
+
+
+def _cases():
+    rng = np.random.default_rng(0)
+    yield "reference scene", rt.scene_rtiow(1)[0]
+    yield "another seed of it", rt.scene_rtiow(3)[0]
+    yield "field of 20 001", rt.scene_field(4, 20000, 0.15, 0.15)[0]
+    yield "field of 200 001", rt.scene_field(5, 200000, 0.15, 0.15)[0]
+    cloud = np.zeros(5000, dtype=rt.SPHERE_DTYPE)
+    cloud["center"] = rng.uniform(-10, 10, (5000, 3))
+    cloud["radius"] = rng.uniform(0.05, 0.2, 5000)
+    yield "cloud", cloud
+    fat = np.zeros(400, dtype=rt.SPHERE_DTYPE)  # heavily overlapping boxes
+    fat["center"] = rng.uniform(-50, 50, (400, 3))
+    fat["radius"] = rng.uniform(0.01, 8, 400)
+    yield "overlapping", fat
+    piles = np.zeros(900, dtype=rt.SPHERE_DTYPE)  # 30 piles of 30 equal spheres: a leaf per pile
+    piles["center"] = np.repeat(rng.uniform(-8.0, 8.0, size=(30, 3)), 30, axis=0)
+    piles["radius"] = 0.4
+    yield "piles", piles
+    prog = np.zeros(180, dtype=rt.SPHERE_DTYPE)  # centres in geometric progression: most of a node's spheres fall into its first bucket
+    prog["center"][:, 0] = 1.2 ** np.arange(180)
+    prog["radius"] = 0.05 * prog["center"][:, 0]
+    yield "progression", prog
+    yield "two", cloud[:2].copy()
+    yield "one", cloud[:1].copy()
+
+
+@pytest.mark.parametrize("name,spheres", list(_cases()), ids=[c[0] for c in _cases()])
+def test_device_built_tree_is_the_oracles_node_by_node(oracle, name, spheres):
+    boxes, kind, soc, leaf, depth = rt.host_bvh(spheres, on_device=True)
+    ob, ok, os_, ol = _oracle_tree(oracle, spheres)
+    assert len(kind) == len(ok), (len(kind), len(ok))
+    assert np.array_equal(kind, ok) and np.array_equal(soc, os_) and np.array_equal(leaf, ol)
+    assert np.array_equal(boxes, ob)
+    hb = rt.host_bvh(spheres)
+    assert depth == hb[4]
+    if name == "piles":
+        assert (soc[kind == 3] > 1).any()  # the case does have leaves of several spheres
