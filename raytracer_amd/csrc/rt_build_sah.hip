@@ -197,8 +197,8 @@ __device__ __forceinline__ void hist_add(Hist* h, int a, int bucket, const Box6&
   atomicAdd(&h->cnt[a][bucket], 1u);
 }
 
-// The node of a segment once its split is known: its links to the parent, and the children that are single spheres.
-// `arr`: the index array that holds the segment after its partition.
+// Where the hierarchy is written.  make_node: the node of a segment once its split is known (its box, its split axis and its
+// links to the parent); make_leaf: a child that is a single sphere.
 struct Links {
   uint32_t *left, *right, *parent_inner, *parent_leaf, *order, *root_id;
   uint8_t* axis;
@@ -279,7 +279,8 @@ __global__ __launch_bounds__(64) void small_kernel(const Seg* __restrict__ roots
       continue;
     }
     // The first 64 spheres of the segment stay in registers through the three passes (bounds, histogram, partition):
-    // most segments have no more.  The index arrays are read and written past the L1 cache (other lanes wrote them).
+    // most segments have no more.  (The index arrays are written by some lanes and read by others a round later: the wave's
+    // own L1 sees its stores, and the fence below keeps the order; the accesses are marked as streaming.)
     const uint32_t p0 = s.lo + lane;
     const bool have0 = p0 < s.hi;
     const uint32_t prim0 = have0 ? __builtin_nontemporal_load(in + p0) : 0u;
