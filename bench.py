@@ -121,7 +121,7 @@ def measured_traffic():
 ORACLE_COUNTS = {
     "c1": (22.578, 1.522), "c2": (22.578, 1.522), "c5": (26.170, 1.505), "c3": (33.729, 1.460), "c4": (46.954, 1.326),
 }
-# name: (spheres, p_lambertian, p_metal, max_fuzz, width, spp, depth, scene seed) -- the sizes the survey's measurement row states
+# name: (spheres, p_lambertian, p_metal, max_fuzz, width, spp, depth, scene seed) -- the sizes the baseline's configurations state
 OTHER_CONFIGS = {
     "c1": (None, 0, 0, 0, 830, 750, 50, 1),
     "c5": (10000, 0.0, 0.5, 0.3, 3840, 128, 200, 5),

@@ -1,9 +1,9 @@
-// BVH construction on the device: the spheres in Morton order, clustered bottom-up
-// (parallel locally-ordered clustering), boxes fitted bottom-up, written straight into
-// the layout the traversal kernels read.  It stands in for BVH::new
-// (src/bvh.rs:44-48) where building on the host would take longer than
-// rendering; the tree differs from the reference's binned-SAH tree, the closest
-// hits do not (they depend on the spheres only).
+// BVH construction on the device.  A hierarchy over the spheres comes from one of two builders -- the reference's own
+// binned surface-area splits (BVH::new, src/bvh.rs:92-266; rt_build_sah.hip), which make the reference's tree, or, here,
+// the spheres in Morton order clustered bottom-up (parallel locally-ordered clustering), which make a different tree over
+// the same spheres: the closest hits do not depend on the tree -- and the back end in this file fits the boxes bottom-up
+// where the builder has not supplied them, numbers the nodes breadth-first and writes them straight into the layout the
+// traversal kernels read.  It stands in for BVH::new (src/bvh.rs:44-48) where building on the host would take longer.
 #include <cstring>
 #include <utility>
 
