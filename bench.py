@@ -134,6 +134,9 @@ def other_configs(rt, torch):
     """Three renders of each of the other configurations (outside the timed region) after a one-sample launch; the median is reported
     (these frames take 20 - 100 ms: a single launch right after scene creation reads up to 10 % low)."""
     out = []
+    # (a process's first build on the device loads the builder's code, 12 ms once; build_ms below is what every later scene costs)
+    ws, wm = rt.scene_field(1, 2000, 1 / 3, 1 / 3, 1.0)
+    rt.BVH(ws, wm, builder=rt.BUILD_AUTO).close()
     for name, (n, pl, pm, fz, width, spp, depth, seed) in OTHER_CONFIGS.items():
         if n is None:
             spheres, materials = rt.scene_rtiow(seed)
