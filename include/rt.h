@@ -158,11 +158,11 @@ int rt_scene_create(const rt_sphere* spheres, size_t n_spheres, const rt_materia
 
 /* rt_scene_create with a choice of tree builder.  RT_BUILD_HOST_SAH is the reference's
  * binned-SAH tree, built by host threads (0.1 s for 10^5 spheres, 0.65 s for 10^6 on 16 cores).
- * RT_BUILD_DEVICE_SAH is the same algorithm on the GPU (5 ms and 17 ms): the same boxes, buckets,
+ * RT_BUILD_DEVICE_SAH is the same algorithm on the GPU (4 ms and 11 ms): the same boxes, buckets,
  * costs and partitions, so the same tree node for node and the same render; where the reference
  * would keep several spheres in one leaf (spheres on top of each other: no split cheaper than
  * the leaf) it cuts the leaf in the middle until every leaf holds one sphere.
- * RT_BUILD_DEVICE_LBVH clusters the spheres bottom-up along their Morton order (19 ms for 10^6):
+ * RT_BUILD_DEVICE_LBVH clusters the spheres bottom-up along their Morton order (13 ms for 10^6):
  * a different tree over the same spheres, so closest hits are the same (exact ties between
  * overlapping spheres aside) while a render takes 4 - 9 % longer.  RT_BUILD_AUTO takes the host
  * builder below 1 024 spheres and RT_BUILD_DEVICE_SAH from there on.  A scene built on the

@@ -126,7 +126,7 @@ std::atomic<uint64_t> g_wavefront_paths{32u << 20};
 #endif
 
 // RT_BUILD_AUTO: scenes of this many spheres or more get their tree from the device's surface-area build, which makes the host
-// builder's tree (1.8 against 2.4 ms here, 2.4 against 25 ms at 10^4 spheres, 17 against 680 ms at 10^6).
+// builder's tree (1.7 against 2.3 ms here, 2.1 against 24 ms at 10^4 spheres, 11 against 680 ms at 10^6).
 constexpr size_t kAutoDeviceBuild = 1024;
 
 // Partial sums of an allocating render call never exceed this; the sample range is cut into fewer chunks instead.

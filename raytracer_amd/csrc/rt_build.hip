@@ -360,18 +360,6 @@ __global__ __launch_bounds__(kThreads) void emit_spheres_kernel(const rt_sphere*
   out_aux[k] = make_double2(1.0 / s.radius, __longlong_as_double((long long)bits));
 }
 
-struct Scratch {
-  void* p = nullptr;
-  ~Scratch() {
-    if (p) (void)hipFree(p);
-  }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-  template <class T>
-  T* as() const {
-    return static_cast<T*>(p);
-  }
-};
-
 #define RTB(call)                   \
   do {                              \
     hipError_t e_ = (call);         \
@@ -467,15 +455,17 @@ hipError_t device_collapse_wide(const void* d_two_wide_nodes, uint32_t n_two_wid
                                 hipStream_t stream) {
   *d_wide_out = nullptr;
   const float4* nodes = static_cast<const float4*>(d_two_wide_nodes);
+  Arena arena_, *const arena = &arena_;
+  arena_.reserve((size_t)n_two_wide * 160 + (4u << 20));
   Scratch roots_a, roots_b, counts, offsets, scan_tmp, all;
-  RTB(roots_a.alloc((size_t)n_two_wide * 4));
-  RTB(roots_b.alloc((size_t)n_two_wide * 4));
-  RTB(counts.alloc((size_t)n_two_wide * 4 + 4));
-  RTB(offsets.alloc((size_t)n_two_wide * 4 + 4));
-  RTB(all.alloc((size_t)n_two_wide * 128));  // at most one wide node per two-wide node; trimmed below
+  RTB(roots_a.alloc((size_t)n_two_wide * 4, arena));
+  RTB(roots_b.alloc((size_t)n_two_wide * 4, arena));
+  RTB(counts.alloc((size_t)n_two_wide * 4 + 4, arena));
+  RTB(offsets.alloc((size_t)n_two_wide * 4 + 4, arena));
+  RTB(all.alloc((size_t)n_two_wide * 128, arena));  // at most one wide node per two-wide node; trimmed below
   size_t tmp_bytes = 0;
   RTB(rocprim::exclusive_scan(nullptr, tmp_bytes, counts.as<uint32_t>(), offsets.as<uint32_t>(), 0u, (size_t)n_two_wide + 1, rocprim::plus<uint32_t>(), stream));
-  RTB(scan_tmp.alloc(tmp_bytes));
+  RTB(scan_tmp.alloc(tmp_bytes, arena));
   const uint32_t zero = 0;
   RTB(hipMemcpyAsync(roots_a.p, &zero, 4, hipMemcpyHostToDevice, stream));  // the root of the two-wide tree is node 0
   uint32_t count = 1, base = 0, levels = 0;
@@ -511,25 +501,27 @@ hipError_t device_build_hierarchy(const rt_sphere* h_spheres, size_t n_, HostHie
   if (n < 2) return hipErrorInvalidValue;
   const uint32_t n_inner = n - 1;
   const unsigned blocks = (n + kThreads - 1) / kThreads;
+  Arena arena_, *const arena = &arena_;
+  arena_.reserve((size_t)n * kBuildScratchPerSphere + (4u << 20));
   Scratch d_in, prim_box, centroid, block_bounds, left, right, parent_inner, parent_leaf, node_box, axis, order, root;
-  RTB(d_in.alloc((size_t)n * sizeof(rt_sphere)));
+  RTB(d_in.alloc((size_t)n * sizeof(rt_sphere), arena));
   RTB(hipMemcpyAsync(d_in.p, h_spheres, (size_t)n * sizeof(rt_sphere), hipMemcpyHostToDevice, stream));
-  RTB(prim_box.alloc((size_t)n * sizeof(Box6)));
-  RTB(centroid.alloc((size_t)n * 24));
-  RTB(block_bounds.alloc((size_t)blocks * 48));
-  RTB(left.alloc((size_t)n_inner * 4));
-  RTB(right.alloc((size_t)n_inner * 4));
-  RTB(parent_inner.alloc((size_t)n_inner * 4));
-  RTB(parent_leaf.alloc((size_t)n * 4));
-  RTB(node_box.alloc((size_t)n_inner * sizeof(Box6)));
-  RTB(axis.alloc(n_inner));
-  RTB(order.alloc((size_t)n * 4));
-  RTB(root.alloc(4));
+  RTB(prim_box.alloc((size_t)n * sizeof(Box6), arena));
+  RTB(centroid.alloc((size_t)n * 24, arena));
+  RTB(block_bounds.alloc((size_t)blocks * 48, arena));
+  RTB(left.alloc((size_t)n_inner * 4, arena));
+  RTB(right.alloc((size_t)n_inner * 4, arena));
+  RTB(parent_inner.alloc((size_t)n_inner * 4, arena));
+  RTB(parent_leaf.alloc((size_t)n * 4, arena));
+  RTB(node_box.alloc((size_t)n_inner * sizeof(Box6), arena));
+  RTB(axis.alloc(n_inner, arena));
+  RTB(order.alloc((size_t)n * 4, arena));
+  RTB(root.alloc(4, arena));
   hipLaunchKernelGGL(boxes_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, prim_box.as<Box6>(), centroid.as<double>(),
                      (const uint8_t*)nullptr, block_bounds.as<double>());
   RTB(hipGetLastError());
   RTB(sah_hierarchy(prim_box.as<Box6>(), centroid.as<double>(), n, left.as<uint32_t>(), right.as<uint32_t>(), parent_inner.as<uint32_t>(),
-                    parent_leaf.as<uint32_t>(), axis.as<uint8_t>(), node_box.as<Box6>(), order.as<uint32_t>(), root.as<uint32_t>(), stream));
+                    parent_leaf.as<uint32_t>(), axis.as<uint8_t>(), node_box.as<Box6>(), order.as<uint32_t>(), root.as<uint32_t>(), arena, stream));
   out->left.resize(n_inner);
   out->right.resize(n_inner);
   out->axis.resize(n_inner);
@@ -552,33 +544,35 @@ hipError_t device_build(const rt_sphere* h_spheres, size_t n_, const uint8_t* h_
   const uint32_t n_inner = n - 1;  // the caller guarantees n >= 2
   const unsigned blocks = (n + kThreads - 1) / kThreads, blocks_inner = (n_inner + kThreads - 1) / kThreads;
 
+  Arena arena_, *const arena = &arena_;  // (declared before the arrays: it outlives them)
+  arena_.reserve((size_t)n * kBuildScratchPerSphere + n_materials + (4u << 20));
   Scratch d_in, d_mtype, prim_box, centroid, block_bounds, bounds, keys, keys2, vals, vals2, left, right, parent_inner, parent_leaf, node_box,
       arrivals, level, level2, ids, order, new_of, misc, sort_tmp, flags;
-  RTB(d_in.alloc((size_t)n * sizeof(rt_sphere)));
-  RTB(d_mtype.alloc(n_materials));
+  RTB(d_in.alloc((size_t)n * sizeof(rt_sphere), arena));
+  RTB(d_mtype.alloc(n_materials, arena));
   RTB(hipMemcpyAsync(d_in.p, h_spheres, (size_t)n * sizeof(rt_sphere), hipMemcpyHostToDevice, stream));
   RTB(hipMemcpyAsync(d_mtype.p, h_material_type, n_materials, hipMemcpyHostToDevice, stream));
-  RTB(prim_box.alloc((size_t)n * sizeof(Box6)));
-  RTB(centroid.alloc((size_t)n * 24));
-  RTB(block_bounds.alloc((size_t)blocks * 48));
-  RTB(bounds.alloc(48));
-  RTB(flags.alloc(n));
-  RTB(keys.alloc((size_t)n * 8));
-  RTB(keys2.alloc((size_t)n * 8));
-  RTB(vals.alloc((size_t)n * 4));
-  RTB(vals2.alloc((size_t)n * 4));
-  RTB(left.alloc((size_t)n_inner * 4));
-  RTB(right.alloc((size_t)n_inner * 4));
-  RTB(parent_inner.alloc((size_t)n_inner * 4));
-  RTB(parent_leaf.alloc((size_t)n * 4));
-  RTB(node_box.alloc((size_t)n_inner * sizeof(Box6)));
-  RTB(arrivals.alloc((size_t)n_inner * 4));
-  RTB(level.alloc((size_t)n_inner * 4));
-  RTB(level2.alloc((size_t)n_inner * 4));
-  RTB(ids.alloc((size_t)n_inner * 4));
-  RTB(order.alloc((size_t)n_inner * 4));
-  RTB(new_of.alloc((size_t)n_inner * 4));
-  RTB(misc.alloc(16));  // [0] deepest level (u32), [1] bound (f32), [2] the root's id (surface-area build)
+  RTB(prim_box.alloc((size_t)n * sizeof(Box6), arena));
+  RTB(centroid.alloc((size_t)n * 24, arena));
+  RTB(block_bounds.alloc((size_t)blocks * 48, arena));
+  RTB(bounds.alloc(48, arena));
+  RTB(flags.alloc(n, arena));
+  RTB(keys.alloc((size_t)n * 8, arena));
+  RTB(keys2.alloc((size_t)n * 8, arena));
+  RTB(vals.alloc((size_t)n * 4, arena));
+  RTB(vals2.alloc((size_t)n * 4, arena));
+  RTB(left.alloc((size_t)n_inner * 4, arena));
+  RTB(right.alloc((size_t)n_inner * 4, arena));
+  RTB(parent_inner.alloc((size_t)n_inner * 4, arena));
+  RTB(parent_leaf.alloc((size_t)n * 4, arena));
+  RTB(node_box.alloc((size_t)n_inner * sizeof(Box6), arena));
+  RTB(arrivals.alloc((size_t)n_inner * 4, arena));
+  RTB(level.alloc((size_t)n_inner * 4, arena));
+  RTB(level2.alloc((size_t)n_inner * 4, arena));
+  RTB(ids.alloc((size_t)n_inner * 4, arena));
+  RTB(order.alloc((size_t)n_inner * 4, arena));
+  RTB(new_of.alloc((size_t)n_inner * 4, arena));
+  RTB(misc.alloc(16, arena));  // [0] deepest level (u32), [1] bound (f32), [2] the root's id (surface-area build)
   RTB(hipMemsetAsync(arrivals.p, 0, (size_t)n_inner * 4, stream));
   RTB(hipMemsetAsync(misc.p, 0, 16, stream));
 
@@ -587,19 +581,19 @@ hipError_t device_build(const rt_sphere* h_spheres, size_t n_, const uint8_t* h_
                                 stream));
   RTB(rocprim::radix_sort_pairs(nullptr, tmp_bytes2, level.as<uint32_t>(), level2.as<uint32_t>(), ids.as<uint32_t>(), order.as<uint32_t>(), n_inner,
                                 0, 8, stream));
-  RTB(sort_tmp.alloc(tmp_bytes > tmp_bytes2 ? tmp_bytes : tmp_bytes2));
+  RTB(sort_tmp.alloc(tmp_bytes > tmp_bytes2 ? tmp_bytes : tmp_bytes2, arena));
 
   Scratch split_axis;
   uint32_t root_id = 0;
   const bool sah = builder == DeviceBuilder::kBinnedSah;
   if (sah) {
     // boxes and centroids, then the hierarchy of the reference's own algorithm (rt_build_sah.hip); leaf k is sphere vals2[k]
-    RTB(split_axis.alloc(n_inner));
+    RTB(split_axis.alloc(n_inner, arena));
     hipLaunchKernelGGL(boxes_kernel, dim3(blocks), dim3(kThreads), 0, stream, d_in.as<rt_sphere>(), n, prim_box.as<Box6>(), centroid.as<double>(),
                        (const uint8_t*)nullptr, block_bounds.as<double>());
     RTB(hipGetLastError());
     RTB(sah_hierarchy(prim_box.as<Box6>(), centroid.as<double>(), n, left.as<uint32_t>(), right.as<uint32_t>(), parent_inner.as<uint32_t>(),
-                      parent_leaf.as<uint32_t>(), split_axis.as<uint8_t>(), node_box.as<Box6>(), vals2.as<uint32_t>(), misc.as<uint32_t>() + 2, stream));
+                      parent_leaf.as<uint32_t>(), split_axis.as<uint8_t>(), node_box.as<Box6>(), vals2.as<uint32_t>(), misc.as<uint32_t>() + 2, arena, stream));
     RTB(hipMemcpyAsync(&root_id, misc.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost, stream));
     RTB(hipStreamSynchronize(stream));
     if (root_id >= n_inner) return hipErrorUnknown;
@@ -621,19 +615,19 @@ hipError_t device_build(const rt_sphere* h_spheres, size_t n_, const uint8_t* h_
 
     // clustering rounds over the Morton order (ping-pong arrays; the host reads the two counts back after every round)
     Scratch ref_a, ref_b, box_a, box_b, nearest, marks, scan, totals;
-    RTB(ref_a.alloc((size_t)n * 4));
-    RTB(ref_b.alloc((size_t)n * 4));
-    RTB(box_a.alloc((size_t)n * sizeof(ClusterBox)));
-    RTB(box_b.alloc((size_t)n * sizeof(ClusterBox)));
-    RTB(nearest.alloc((size_t)n * 4));
-    RTB(marks.alloc((size_t)n * 8));
-    RTB(scan.alloc((size_t)n * 8));
-    RTB(totals.alloc(8));
+    RTB(ref_a.alloc((size_t)n * 4, arena));
+    RTB(ref_b.alloc((size_t)n * 4, arena));
+    RTB(box_a.alloc((size_t)n * sizeof(ClusterBox), arena));
+    RTB(box_b.alloc((size_t)n * sizeof(ClusterBox), arena));
+    RTB(nearest.alloc((size_t)n * 4, arena));
+    RTB(marks.alloc((size_t)n * 8, arena));
+    RTB(scan.alloc((size_t)n * 8, arena));
+    RTB(totals.alloc(8, arena));
     size_t scan_bytes = 0;
     RTB(rocprim::exclusive_scan(nullptr, scan_bytes, marks.as<unsigned long long>(), scan.as<unsigned long long>(), 0ull, n,
                                 rocprim::plus<unsigned long long>(), stream));
     Scratch scan_tmp;
-    RTB(scan_tmp.alloc(scan_bytes));
+    RTB(scan_tmp.alloc(scan_bytes, arena));
     hipLaunchKernelGGL(ploc_init_kernel, dim3(blocks), dim3(kThreads), 0, stream, prim_box.as<Box6>(), vals2.as<uint32_t>(), n, ref_a.as<uint32_t>(),
                        box_a.as<ClusterBox>());
     uint32_t m = n, next_id = 0;

@@ -636,18 +636,6 @@ __global__ __launch_bounds__(kBlock) void iota_kernel(uint32_t* __restrict__ idx
   if (i < n) idx[i] = i;
 }
 
-struct Scratch {
-  void* p = nullptr;
-  ~Scratch() {
-    if (p) (void)hipFree(p);
-  }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-  template <class T>
-  T* as() const {
-    return static_cast<T*>(p);
-  }
-};
-
 #define RTB(call)                    \
   do {                               \
     hipError_t e_ = (call);          \
@@ -657,20 +645,20 @@ struct Scratch {
 }  // namespace
 
 hipError_t sah_hierarchy(const Box6* prim_box, const double* centroid, uint32_t n, uint32_t* left, uint32_t* right, uint32_t* parent_inner,
-                         uint32_t* parent_leaf, uint8_t* axis, Box6* node_box, uint32_t* order, uint32_t* root_id, hipStream_t stream) {
+                         uint32_t* parent_leaf, uint8_t* axis, Box6* node_box, uint32_t* order, uint32_t* root_id, Arena* arena, hipStream_t stream) {
   if (n < 2) return hipErrorInvalidValue;
   const uint32_t max_big = n / kSmall + 2, max_small = n / 2 + 2, max_chunks = n / kChunk + max_big + 2;
   Scratch idx0, idx1, segs_a, segs_b, small, acc, dec, chunk_off, chunk_left, counts;
-  RTB(idx0.alloc((size_t)n * 4));
-  RTB(idx1.alloc((size_t)n * 4));
-  RTB(segs_a.alloc((size_t)max_big * sizeof(Seg)));
-  RTB(segs_b.alloc((size_t)max_big * sizeof(Seg)));
-  RTB(small.alloc((size_t)max_small * sizeof(Seg)));
-  RTB(acc.alloc((size_t)max_big * sizeof(BigAcc)));
-  RTB(dec.alloc((size_t)max_big * sizeof(BigDecision)));
-  RTB(chunk_off.alloc((size_t)(max_big + 1) * 4));
-  RTB(chunk_left.alloc((size_t)max_chunks * 4));
-  RTB(counts.alloc(16));  // [0] segments of the next level, [1] segments for the small kernel, [2] chunks of the next level
+  RTB(idx0.alloc((size_t)n * 4, arena));
+  RTB(idx1.alloc((size_t)n * 4, arena));
+  RTB(segs_a.alloc((size_t)max_big * sizeof(Seg), arena));
+  RTB(segs_b.alloc((size_t)max_big * sizeof(Seg), arena));
+  RTB(small.alloc((size_t)max_small * sizeof(Seg), arena));
+  RTB(acc.alloc((size_t)max_big * sizeof(BigAcc), arena));
+  RTB(dec.alloc((size_t)max_big * sizeof(BigDecision), arena));
+  RTB(chunk_off.alloc((size_t)(max_big + 1) * 4, arena));
+  RTB(chunk_left.alloc((size_t)max_chunks * 4, arena));
+  RTB(counts.alloc(16, arena));  // [0] segments of the next level, [1] segments for the small kernel, [2] chunks of the next level
   RTB(hipMemsetAsync(counts.p, 0, 16, stream));
   hipLaunchKernelGGL(iota_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, idx0.as<uint32_t>(), n);  // ascending sphere order, as on the host
   const Links L{left, right, parent_inner, parent_leaf, order, root_id, axis, node_box};
