@@ -190,12 +190,14 @@ def test_device_list_is_checked(rtiow):
         rt.BVH(*rtiow, devices=[])
 
 
-def test_multi_scene_through_the_four_wide_walk_and_device_builder():
+@pytest.mark.parametrize("builder", [rt.BUILD_DEVICE_LBVH, rt.BUILD_DEVICE_SAH, rt.BUILD_AUTO])
+def test_multi_scene_through_the_four_wide_walk_and_device_builder(builder):
     # a scene that does not fit in LDS, copies built on the device: tiles still bit-identical, samples to rounding
     spheres, materials = rt.scene_field(3, 20000, 1.0 / 3.0, 1.0 / 3.0)
-    one = rt.BVH(spheres, materials, builder=rt.BUILD_DEVICE_LBVH)
-    two = rt.BVH(spheres, materials, builder=rt.BUILD_DEVICE_LBVH, devices=[0, 0])
-    assert two.info()["n_devices"] == 2 and two.info()["builder"] == rt.BUILD_DEVICE_LBVH
+    one = rt.BVH(spheres, materials, builder=builder)
+    two = rt.BVH(spheres, materials, builder=builder, devices=[0, 0])
+    made_by = rt.BUILD_DEVICE_SAH if builder == rt.BUILD_AUTO else builder
+    assert two.info()["n_devices"] == 2 and two.info()["builder"] == made_by and one.info()["builder"] == made_by
     cam = rt.config_field(20000, 120, 20, 50).camera()
     want, st = cam.render_sum(one, seed=3)
     got, st2 = cam.render_multi(two, seed=3, partition=rt.PARTITION_TILES)

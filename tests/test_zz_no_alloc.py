@@ -60,9 +60,9 @@ def test_no_alloc_entry_point_on_a_scene_walked_through_the_four_wide_tree():
     import torch
 
     n = 60000
-    world = rt.BVH(*rt.scene_field(7, n, 0.3, 0.3, 0.5))
+    world = rt.BVH(*rt.scene_field(7, n, 0.3, 0.3, 0.5), builder=rt.BUILD_AUTO)  # (built on the device, as rt_scene_create would)
     info = world.info()
-    assert info["n_nodes_in_lds"] < info["n_device_nodes"]
+    assert info["n_nodes_in_lds"] < info["n_device_nodes"] and info["builder"] == rt.BUILD_DEVICE_SAH
     for width, spp, seed in ((160, 16, 5), (96, 6, 6)):
         cam = rt.config_field(n, width, spp, 30).camera()
         want = torch.zeros((cam.image_height, width, 3), dtype=torch.float64, device="cuda")
