@@ -117,3 +117,24 @@ def test_device_built_tree_is_the_oracles_node_by_node(oracle, name, spheres):
     assert depth == hb[4]
     if name == "piles":
         assert (soc[kind == 3] > 1).any()  # the case does have leaves of several spheres
+
+
+def test_the_largest_scene_the_library_takes():
+    # 16 777 199 spheres (rt_scene_create's limit): built on the device by both builders; closest hits do not depend on the tree,
+    # so the two frames and ray counts must agree bit for bit
+    n = 16777199
+    spheres, materials = rt.scene_field(4, n - 1, 0.15, 0.15, 1.0)
+    cam = rt.config_field(n - 1, 640, 4, 50).camera()
+    out = []
+    for builder in (rt.BUILD_DEVICE_SAH, rt.BUILD_DEVICE_LBVH):
+        w = rt.BVH(spheres, materials, builder=builder)
+        try:
+            info = w.info()
+            assert info["n_spheres"] == n and info["builder"] == builder
+            out.append(cam.render_sum(w, seed=9) + (info["build_ms"],))
+        finally:
+            w.close()
+    (a, sa, ms_a), (b, sb, ms_b) = out
+    print("%d spheres: surface-area build %.0f ms, clustering build %.0f ms, %d rays" % (n, ms_a, ms_b, sa["rays"]))
+    assert sa["rays"] == sb["rays"] and sa["rays"] > 640 * 360 * 4 and np.array_equal(a, b)
+    assert np.isfinite(a).all() and a.min() >= 0.0

@@ -34,6 +34,19 @@ def test_no_cpu_fallback():
         pytest.skip("a GPU is present")
 
 
+def test_scenes_beyond_the_documented_limits_are_refused():
+    # one sphere more than rt_scene_create takes (include/rt.h): refused with RT_ERR_LIMIT before anything is read or built
+    spheres = np.zeros(16777200, dtype=rt.SPHERE_DTYPE)
+    materials = np.zeros(1, dtype=rt.MATERIAL_DTYPE)
+    for builder in (rt.BUILD_HOST_SAH, rt.BUILD_DEVICE_LBVH, rt.BUILD_DEVICE_SAH, rt.BUILD_AUTO):
+        with pytest.raises(rt.RtError) as e:
+            rt.BVH(spheres, materials, builder=builder)
+        assert e.value.code == 4 and "16777199" in str(e.value)
+    with pytest.raises(rt.RtError) as e:
+        rt.host_bvh(spheres, on_device=True)
+    assert e.value.code == 4
+
+
 def _same_tree(oracle, spheres):
     boxes, kind, soc, leaf, depth = rt.host_bvh(spheres)
     materials = np.zeros(1, dtype=oracle.MATERIAL_DTYPE)
