@@ -27,7 +27,6 @@ def area(lo, hi):
 
 def span(kind, soc, i):
     """Nodes of the subtree rooted at i in the pre-order array (skip = distance to the right child)."""
-    n = 1
     j = i
     while kind[j] != 3:  # follow right children to the subtree's end
         j = j + int(soc[j])
@@ -43,22 +42,17 @@ def main():
         lo, hi = boxes[:, :3], boxes[:, 3:]
         inner = np.nonzero(kind != 3)[0]
         left, right = inner + 1, inner + soc[inner].astype(np.int64)
-        # the ground (a sphere as large as the scene, cut out of the device's tree) and its ancestors are left out: the tree below
-        root = 0
-        big = np.argmax(area(lo, hi)[kind == 3])
         sa = area(lo, hi)
-        whole = sa[root]
+        whole = sa[0]
         # overlap of the two children of every split
         olo, ohi = np.maximum(lo[left], lo[right]), np.minimum(hi[left], hi[right])
         overlap = np.where((ohi >= olo).all(axis=1), area(olo, ohi), 0.0)
-        # leave out splits one of whose children is the scene-sized leaf (the device's copy of the tree does not have them)
         # splits at or above the scene-sized leaf (a one-sphere leaf with more than half the tree's area: the ground) are left out, as
         # the device's copy of the tree leaves that sphere out: what remains is the tree over the small spheres
         ground = np.nonzero((kind == 3) & (sa > 0.5 * whole))[0]
         keep = np.ones(len(inner), dtype=bool)
         if len(ground):
             g = ground[0]
-            keep = ~((inner < g) & (inner + np.array([subtree_size(kind, soc, i) for i in inner[:64]] + [0] * max(0, len(inner) - 64)) > g)) if False else keep
             above = [i for i in inner[:4096] if i < g < i + span(kind, soc, i)]
             keep[np.isin(inner, above)] = False
         ref = sa[inner][keep].max()  # the tree below the scene-sized leaf
