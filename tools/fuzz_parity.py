@@ -28,7 +28,7 @@ def random_scene(rng):
     n = int(rng.choice([1, 2, 3, 7, 40, 300, 2000, 6000]))
     if kind == 0:  # the library's field generator
         n = max(n, 4)
-        return rt.scene_field(int(rng.integers(1, 1 << 30)), n, float(rng.uniform(0, 0.6)), float(rng.uniform(0, 0.4)), float(rng.uniform(0, 1)))
+        return rt.scene_field(int(rng.integers(1, 1 << 30)), n, float(rng.uniform(0, 0.6)), float(rng.uniform(0, 0.4)), float(rng.uniform(0, 1))) + (False,)
     spheres = np.zeros(n, dtype=rt.SPHERE_DTYPE)
     materials = np.zeros(max(1, min(n, int(rng.integers(1, 9)))), dtype=rt.MATERIAL_DTYPE)
     if kind == 1:  # a cloud
@@ -50,7 +50,8 @@ def random_scene(rng):
     materials["type"] = rng.integers(0, 3, len(materials))
     materials["albedo"] = rng.uniform(0, 1, (len(materials), 3))
     materials["param"] = np.where(materials["type"] == 2, rng.uniform(1.1, 2.4, len(materials)), rng.uniform(0, 1, len(materials)))
-    return spheres, materials
+    # thousands of boxes inside each other: no tree helps, every ray tests most of the spheres (the oracle needs minutes for a frame)
+    return spheres, materials, kind >= 3 and n >= 2000
 
 
 def random_config(rng, spheres):
@@ -91,7 +92,7 @@ def main():
     rng = np.random.default_rng(a.seed)
     t_start = time.time()
     for case in range(a.cases):
-        spheres, materials = random_scene(rng)
+        spheres, materials, heavy = random_scene(rng)
         builder = (rt.BUILD_HOST_SAH, rt.BUILD_DEVICE_LBVH, rt.BUILD_DEVICE_SAH)[int(rng.integers(0, 3))]
         world = rt.BVH(spheres, materials, builder=builder)
         oworld = orc.Scene(spheres.view(orc.SPHERE_DTYPE), materials.view(orc.MATERIAL_DTYPE))
@@ -112,6 +113,10 @@ def main():
         tile = (x0, y0, int(rng.integers(x0 + 1, w + 1)), int(rng.integers(y0 + 1, h + 1))) if rng.random() < 0.5 else None
         s0 = int(rng.integers(0, spp))
         s1 = int(rng.integers(s0 + 1, spp + 1))
+        if heavy:  # a small rectangle, two samples at most
+            s1 = min(s1, s0 + 2)
+            x0, y0 = (tile[0], tile[1]) if tile else (0, 0)
+            tile = (x0, y0, min(w, x0 + 12), min(h, y0 + 12))
         seed = int(rng.integers(0, 1 << 62))
         # Paths are chaotic: after some ten bounces off curved glass a last-bit difference (the device contracts
         # multiply-adds, the oracle does not) sends a path elsewhere.  So the pixel-for-pixel comparison is made with
