@@ -738,19 +738,20 @@ __device__ __forceinline__ WideData wide_fetch(const Trav& tr, const TreeView& t
   } else {
     const char* base = reinterpret_cast<const char*>(tv.gnodes);
     const uint32_t at = node * 128u;
+    // (the constant parts of the offsets are added to the 64-bit addresses, where they fold into the load instructions)
     w.NX = *reinterpret_cast<const f32x4*>(base + (size_t)(at + tr.offx));
     w.FX = *reinterpret_cast<const f32x4*>(base + (size_t)(at + (tr.offx ^ 16u)));
-    w.NY = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 32u + tr.offy));
-    w.FY = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 32u + (tr.offy ^ 16u)));
-    w.NZ = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 64u + tr.offz));
-    w.FZ = *reinterpret_cast<const f32x4*>(base + (size_t)(at + 64u + (tr.offz ^ 16u)));
-    w.refs = *reinterpret_cast<const u32x4*>(base + (size_t)(at + 96u));
+    w.NY = *reinterpret_cast<const f32x4*>(base + (size_t)(at + tr.offy) + 32);
+    w.FY = *reinterpret_cast<const f32x4*>(base + (size_t)(at + (tr.offy ^ 16u)) + 32);
+    w.NZ = *reinterpret_cast<const f32x4*>(base + (size_t)(at + tr.offz) + 64);
+    w.FZ = *reinterpret_cast<const f32x4*>(base + (size_t)(at + (tr.offz ^ 16u)) + 64);
+    w.refs = *reinterpret_cast<const u32x4*>(base + (size_t)at + 96);
   }
   return w;
 }
 struct WideChoice {
-  bool h0, h1, h2, h3, is0;
-  uint32_t first, next;
+  bool h0, h1, h2, h3, is0, f1, f2, f3;
+  uint32_t next;
 };
 __device__ __forceinline__ WideChoice wide_choose(const Trav& tr, const WideData& w) {
   const f32x4 &NX = w.NX, &FX = w.FX, &NY = w.NY, &FY = w.FY, &NZ = w.NZ, &FZ = w.FZ;
@@ -775,17 +776,45 @@ __device__ __forceinline__ WideChoice wide_choose(const Trav& tr, const WideData
   // the child entered first (the lowest of equals); selects, not branches
   c.is0 = t0 == m;
   const bool is1 = t1 == m, is2 = t2 == m;
-  c.first = c.is0 ? 0u : is1 ? 1u : is2 ? 2u : 3u;
-  c.next = c.is0 ? refs.x : is1 ? refs.y : is2 ? refs.z : refs.w;
+  c.f1 = !c.is0 && is1;
+  c.f2 = !c.is0 && !is1 && is2;
+  c.f3 = !c.is0 && !is1 && !is2;
+  uint32_t nx = refs.w;
+  nx = c.f2 ? refs.z : nx;
+  nx = c.f1 ? refs.y : nx;
+  c.next = c.is0 ? refs.x : nx;
   return c;
 }
 __device__ __forceinline__ void wide_apply(Trav& tr, const HybridStack& st, const u32x4& refs, const WideChoice& c) {
   // The others that are hit wait on the stack, pushed in the order 3, 2, 1, 0 (last pushed, first visited: the
   // later children of a node come from the larger subtree that was opened up).  (Measured: storing to three slots
   // unconditionally instead of these branches, and one generic load sequence for LDS and global nodes, were both slower.)
-  if (c.h3 && c.first != 3u) trav_push(tr, st, refs.w);
-  if (c.h2 && c.first != 2u) trav_push(tr, st, refs.z);
-  if (c.h1 && c.first != 1u) trav_push(tr, st, refs.y);
+  if (__builtin_amdgcn_ballot_w64(tr.sp + 3u > st.k) == 0) {
+    // no lane of the wave can leave the part of its stack that is in LDS in this step: pushes and the pop without the test for it
+    const uint32_t base = (uint32_t)(uintptr_t)st.l;  // (LDS pointers are 32 bits wide)
+    uint32_t a = base + tr.sp * (4u * kWorkgroup);
+    const auto push = [&](uint32_t ref) {
+      *(lds_u32*)(uintptr_t)a = tr.tos;
+      a += 4u * kWorkgroup;
+      tr.tos = ref;
+    };
+    if (c.h3 && !c.f3) push(refs.w);
+    if (c.h2 && !c.f2) push(refs.z);
+    if (c.h1 && !c.f1) push(refs.y);
+    if (c.h0 && !c.is0) push(refs.x);
+    tr.sp = (a - base) / (4u * kWorkgroup);
+    if (c.h0 || c.h1 || c.h2 || c.h3) {
+      tr.cur = c.next;
+    } else {
+      tr.cur = tr.tos;
+      tr.sp = __builtin_elementwise_sub_sat(tr.sp, 1u);
+      tr.tos = *hs_slot_l(st, tr.sp);
+    }
+    return;
+  }
+  if (c.h3 && !c.f3) trav_push(tr, st, refs.w);
+  if (c.h2 && !c.f2) trav_push(tr, st, refs.z);
+  if (c.h1 && !c.f1) trav_push(tr, st, refs.y);
   if (c.h0 && !c.is0) trav_push(tr, st, refs.x);
   if (c.h0 || c.h1 || c.h2 || c.h3) {
     tr.cur = c.next;

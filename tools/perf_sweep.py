@@ -31,7 +31,7 @@ if a.config:
 else:
     spheres, materials = rt.scene_rtiow(1)
     cfg = rt.config_rtiow(a.width, a.spp, 50)
-SCENE_KNOBS = ("first_leaf", "force_wide", "force_global_stack")  # read when a scene is created: the scene is rebuilt per value
+SCENE_KNOBS = ("first_leaf", "force_wide", "force_global_stack", "wide_lds_stack")  # read when a scene is created: the scene is rebuilt per value
 world = rt.BVH(spheres, materials, builder=a.builder)
 cam = cfg.camera()
 frame = torch.zeros((cam.image_height, a.width, 3), dtype=torch.float64, device="cuda")
