@@ -738,15 +738,19 @@ __device__ __forceinline__ WideData wide_fetch(const Trav& tr, const TreeView& t
   } else {
     const char* base = reinterpret_cast<const char*>(tv.gnodes);
     const uint32_t at = node * 128u;
-    // (the constant parts of the offsets are added to the 64-bit addresses, where they fold into the load instructions)
-    w.NX = *reinterpret_cast<const f32x4*>(base + (size_t)(at + tr.offx));
-    w.FX = *reinterpret_cast<const f32x4*>(base + (size_t)(at + (tr.offx ^ 16u)));
-    w.NY = *reinterpret_cast<const f32x4*>(base + (size_t)(at + tr.offy) + 32);
-    w.FY = *reinterpret_cast<const f32x4*>(base + (size_t)(at + (tr.offy ^ 16u)) + 32);
-    w.NZ = *reinterpret_cast<const f32x4*>(base + (size_t)(at + tr.offz) + 64);
-    w.FZ = *reinterpret_cast<const f32x4*>(base + (size_t)(at + (tr.offz ^ 16u)) + 64);
-    w.refs = *reinterpret_cast<const u32x4*>(base + (size_t)at + 96);
+    // The loads are written out so that the compiler does not know them for loads: both branches write the same
+    // registers, in different lanes, and the compiler would have the LDS reads of the other lanes wait until these loads
+    // have landed.  wide_landed() waits for them.
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(w.NX) : "v"(at + tr.offx), "s"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(w.FX) : "v"(at + (tr.offx ^ 16u)), "s"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=&v"(w.NY) : "v"(at + tr.offy), "s"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=&v"(w.FY) : "v"(at + (tr.offy ^ 16u)), "s"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=&v"(w.NZ) : "v"(at + tr.offz), "s"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=&v"(w.FZ) : "v"(at + (tr.offz ^ 16u)), "s"(base) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:96" : "=&v"(w.refs) : "v"(at), "s"(base) : "memory");
   }
+  // every lane: the loads above have landed when this returns (the LDS reads are the compiler's to wait for)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(w.NX), "+v"(w.FX), "+v"(w.NY), "+v"(w.FY), "+v"(w.NZ), "+v"(w.FZ), "+v"(w.refs) : : "memory");
   return w;
 }
 struct WideChoice {
