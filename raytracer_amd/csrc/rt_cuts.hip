@@ -122,16 +122,20 @@ __global__ __launch_bounds__(64) void tile_cuts_kernel(SceneDev sc, CameraDev ca
   uint32_t n_out = 0;
   auto write = [&]() {
     uint32_t* dst = cuts + (size_t)t * (kEntries * kWords);
-    for (uint32_t k = 0; k < kEntries; ++k) {
-      const bool used = k < n_out;
-      dst[k * kWords] = used ? out[k].ref : kRefNone;
-      if constexpr (kWords == 8u) {
+    if constexpr (kWide) {  // groups of four entries in the form of a staged four-wide node (rt_launch.h)
+      const float inf = __builtin_inff();
+      for (uint32_t k = 0; k < kEntries; ++k) {
+        const bool used = k < n_out;
+        uint32_t* g = dst + (k / 4u) * kWideCutGroupWords + (k & 3u);
         for (int a = 0; a < 3; ++a) {
-          dst[k * kWords + 1 + a] = __float_as_uint(used ? out[k].lo[a] : 0.0f);
-          dst[k * kWords + 4 + a] = __float_as_uint(used ? out[k].hi[a] : 0.0f);
+          g[8 * a] = __float_as_uint(used ? out[k].lo[a] : inf);
+          g[8 * a + 4] = __float_as_uint(used ? out[k].hi[a] : -inf);
         }
-        dst[k * kWords + 7] = 0u;
+        g[24] = used ? out[k].ref : kRefNone;
       }
+      for (uint32_t w = (kEntries / 4u) * kWideCutGroupWords; w < kEntries * kWords; ++w) dst[w] = 0u;
+    } else {
+      for (uint32_t k = 0; k < kEntries; ++k) dst[k] = k < n_out ? out[k].ref : kRefNone;
     }
   };
   const uint32_t root = sc.root;

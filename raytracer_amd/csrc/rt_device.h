@@ -722,19 +722,24 @@ struct WideData {
   f32x4 NX, FX, NY, FY, NZ, FZ;  // per axis the four children's planes met first and those met last
   u32x4 refs;
 };
+typedef __attribute__((address_space(3))) char lds_char;
+// A node staged in LDS at p (also a group of a tile's entry list, which has the same form).
+__device__ __forceinline__ WideData wide_fetch_lds(const Trav& tr, lds_char* p) {
+  WideData w;
+  w.NX = *(lds_float4*)(p + tr.offx);
+  w.FX = *(lds_float4*)(p + (tr.offx ^ 16u));
+  w.NY = *(lds_float4*)(p + 32u + tr.offy);
+  w.FY = *(lds_float4*)(p + 32u + (tr.offy ^ 16u));
+  w.NZ = *(lds_float4*)(p + 64u + tr.offz);
+  w.FZ = *(lds_float4*)(p + 64u + (tr.offz ^ 16u));
+  w.refs = *(lds_u32x4*)(p + 96);
+  return w;
+}
 __device__ __forceinline__ WideData wide_fetch(const Trav& tr, const TreeView& tv, uint32_t node) {
   // tr.offx/y/z: 16 where the ray travels down the axis (its near planes are the high ones), else 0
   WideData w;
   if (node < tv.n_lds) {
-    typedef __attribute__((address_space(3))) char lds_char;
-    lds_char* p = (lds_char*)tv.lnodes + __umul24(node, kWideLdsStride);
-    w.NX = *(lds_float4*)(p + tr.offx);
-    w.FX = *(lds_float4*)(p + (tr.offx ^ 16u));
-    w.NY = *(lds_float4*)(p + 32u + tr.offy);
-    w.FY = *(lds_float4*)(p + 32u + (tr.offy ^ 16u));
-    w.NZ = *(lds_float4*)(p + 64u + tr.offz);
-    w.FZ = *(lds_float4*)(p + 64u + (tr.offz ^ 16u));
-    w.refs = *(lds_u32x4*)(p + 96);
+    w = wide_fetch_lds(tr, (lds_char*)tv.lnodes + __umul24(node, kWideLdsStride));
   } else {
     const char* base = reinterpret_cast<const char*>(tv.gnodes);
     const uint32_t at = node * 128u;
@@ -757,25 +762,36 @@ struct WideChoice {
   bool h0, h1, h2, h3, is0, f1, f2, f3;
   uint32_t next;
 };
-__device__ __forceinline__ WideChoice wide_choose(const Trav& tr, const WideData& w) {
+// The node test for the four boxes: where the ray enters each and whether it can hit it.
+struct WideTimes {
+  float tn0, tn1, tn2, tn3;
+  bool h0, h1, h2, h3;
+};
+__device__ __forceinline__ WideTimes wide_times(const Trav& tr, const WideData& w) {
   const f32x4 &NX = w.NX, &FX = w.FX, &NY = w.NY, &FY = w.FY, &NZ = w.NZ, &FZ = w.FZ;
-  const u32x4& refs = w.refs;
   const RayBox& q = tr.q;
-  const float tn0 = max3_raw(fmaf(NX.x, q.rx, q.nx.x), fmaf(NY.x, q.ry, q.ny.x), fma_clamp(NZ.x, q.rz, q.nz.x));
-  const float tn1 = max3_raw(fmaf(NX.y, q.rx, q.nx.x), fmaf(NY.y, q.ry, q.ny.x), fma_clamp(NZ.y, q.rz, q.nz.x));
-  const float tn2 = max3_raw(fmaf(NX.z, q.rx, q.nx.x), fmaf(NY.z, q.ry, q.ny.x), fma_clamp(NZ.z, q.rz, q.nz.x));
-  const float tn3 = max3_raw(fmaf(NX.w, q.rx, q.nx.x), fmaf(NY.w, q.ry, q.ny.x), fma_clamp(NZ.w, q.rz, q.nz.x));
+  WideTimes t;
+  t.tn0 = max3_raw(fmaf(NX.x, q.rx, q.nx.x), fmaf(NY.x, q.ry, q.ny.x), fma_clamp(NZ.x, q.rz, q.nz.x));
+  t.tn1 = max3_raw(fmaf(NX.y, q.rx, q.nx.x), fmaf(NY.y, q.ry, q.ny.x), fma_clamp(NZ.y, q.rz, q.nz.x));
+  t.tn2 = max3_raw(fmaf(NX.z, q.rx, q.nx.x), fmaf(NY.z, q.ry, q.ny.x), fma_clamp(NZ.z, q.rz, q.nz.x));
+  t.tn3 = max3_raw(fmaf(NX.w, q.rx, q.nx.x), fmaf(NY.w, q.ry, q.ny.x), fma_clamp(NZ.w, q.rz, q.nz.x));
   const float tf0 = min3_raw(fmaf(FX.x, q.rx, q.nx.y), fmaf(FY.x, q.ry, q.ny.y), min_raw(fmaf(FZ.x, q.rz, q.nz.y), tr.tmaxf));
   const float tf1 = min3_raw(fmaf(FX.y, q.rx, q.nx.y), fmaf(FY.y, q.ry, q.ny.y), min_raw(fmaf(FZ.y, q.rz, q.nz.y), tr.tmaxf));
   const float tf2 = min3_raw(fmaf(FX.z, q.rx, q.nx.y), fmaf(FY.z, q.ry, q.ny.y), min_raw(fmaf(FZ.z, q.rz, q.nz.y), tr.tmaxf));
   const float tf3 = min3_raw(fmaf(FX.w, q.rx, q.nx.y), fmaf(FY.w, q.ry, q.ny.y), min_raw(fmaf(FZ.w, q.rz, q.nz.y), tr.tmaxf));
-  WideChoice c;
-  c.h0 = tn0 <= tf0, c.h1 = tn1 <= tf1, c.h2 = tn2 <= tf2, c.h3 = tn3 <= tf3;
   // (a node has at least two children; an absent child's box is inverted and infinite, so it is never hit:
   // inf * r + c is +inf on its near side and -inf on its far side, or NaN on both, which the min/max drop, on an
   // axis the ray does not move along -- never on all three)
+  t.h0 = t.tn0 <= tf0, t.h1 = t.tn1 <= tf1, t.h2 = t.tn2 <= tf2, t.h3 = t.tn3 <= tf3;
+  return t;
+}
+__device__ __forceinline__ WideChoice wide_choose(const Trav& tr, const WideData& w) {
+  const u32x4& refs = w.refs;
+  const WideTimes x = wide_times(tr, w);
+  WideChoice c;
+  c.h0 = x.h0, c.h1 = x.h1, c.h2 = x.h2, c.h3 = x.h3;
   const float inf = __builtin_inff();
-  const float t0 = c.h0 ? tn0 : inf, t1 = c.h1 ? tn1 : inf, t2 = c.h2 ? tn2 : inf, t3 = c.h3 ? tn3 : inf;
+  const float t0 = c.h0 ? x.tn0 : inf, t1 = c.h1 ? x.tn1 : inf, t2 = c.h2 ? x.tn2 : inf, t3 = c.h3 ? x.tn3 : inf;
   const float m = min3_raw(t0, t1, min_raw(t2, t3));
   // the child entered first (the lowest of equals); selects, not branches
   c.is0 = t0 == m;

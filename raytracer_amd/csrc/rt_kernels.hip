@@ -369,16 +369,20 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
             if ((unit >> kSlotShift) < kCutRing) {  // the walk starts at the tile's entry list: the nearest entry now, the others set aside
               const lds_u32* list = my_ring + (unit >> kSlotShift) * kSlotWords;
               if constexpr (kWide) {
-                // the entries whose own box the ray can hit are set aside, the farthest first; then the nearest is taken up
+                // the entries whose own box the ray can hit are set aside, the farthest first; then the nearest is taken up.
+                // A group of four entries is read and tested like a node (rt_launch.h).
                 tr.cur = kRefDone;
 #pragma unroll
-                for (int k = (int)kWideCutEntries - 1; k >= 0; --k) {
-                  const u32x4 a = *(const lds_u32x4*)(list + 8 * k);
-                  const f32x4 hi = *(const lds_float4*)(list + 8 * k + 4);
-                  float tn;
-                  if (a.x != kRefDone && box_test(tr.q, f32x2{__uint_as_float(a.y), hi.x}, f32x2{__uint_as_float(a.z), hi.y},
-                                                  f32x2{__uint_as_float(a.w), hi.z}, 0.0f, tr.tmaxf, tn))
-                    trav_push(tr, RTA_STACK, a.x);
+                for (int g = (int)kWideCutEntries / 4 - 1; g >= 0; --g) {
+                  const lds_u32* group = list + g * kWideCutGroupWords;
+                  if (group[24] != kRefDone) {  // entries fill a list from the front: the group has any
+                    const WideData w = wide_fetch_lds(tr, (lds_char*)group);
+                    const WideTimes x = wide_times(tr, w);
+                    if (x.h3) trav_push(tr, RTA_STACK, w.refs.w);
+                    if (x.h2) trav_push(tr, RTA_STACK, w.refs.z);
+                    if (x.h1) trav_push(tr, RTA_STACK, w.refs.y);
+                    if (x.h0) trav_push(tr, RTA_STACK, w.refs.x);
+                  }
                 }
                 trav_pop(tr, RTA_STACK, 0u);
               } else {

@@ -97,13 +97,18 @@ size_t lds_fixed_bytes(bool wide);
 constexpr uint32_t kCutEntries = 4;
 constexpr uint32_t kCutRing = 3;  // tiles whose entry lists a wave keeps at hand (the current batch's and the two before it)
 // Scenes walked through the four-wide tree (where a node step costs a trip to L1 or L2) get longer lists whose entries
-// carry the node's own box, 8 words each: ref, box low xyz, box high xyz (f32, rounded outwards), 0.  A camera ray tests
-// the boxes when it starts and sets aside only the entries it can hit.  (Measured on 10^4 .. 10^6 spheres: lists of 6 and
-// of 12 within 1.5 % of 8; a list per quarter of a tile, which takes four times the LDS, 1 - 7 % slower.)
+// carry the node's own box (f32, rounded outwards).  A camera ray tests the boxes when it starts and sets aside only the
+// entries it can hit.  A list is laid out as groups of four entries in the form of a staged four-wide node (28 words: per
+// axis the four low planes and the four high planes, then the four references; an absent entry has an inverted infinite
+// box and the reference 0xffffffff), so that a lane reads a group as it reads a node -- by direction, seven reads asked
+// for at once -- and tests it with the node test.  Entries fill a list from the front.  (Measured on 10^4 .. 10^6 spheres:
+// lists of 6 and of 12 within 1.5 % of 8; a list per quarter of a tile, which takes four times the LDS, 1 - 7 % slower.)
 #ifndef RTA_WIDE_CUT_ENTRIES  // (overridden by tools/build_variant.sh for measurements)
 #define RTA_WIDE_CUT_ENTRIES 8
 #endif
 constexpr uint32_t kWideCutEntries = RTA_WIDE_CUT_ENTRIES;
+static_assert(kWideCutEntries % 4 == 0, "lists of the four-wide walk are made of groups of four entries");
+constexpr uint32_t kWideCutGroupWords = 28;  // one group: 7 x 16 bytes, the staged form of a four-wide node
 constexpr uint32_t cut_entries(bool wide) { return wide ? kWideCutEntries : kCutEntries; }
 constexpr uint32_t cut_entry_words(bool wide) { return wide ? 8u : 1u; }
 constexpr uint32_t cut_tile_words(bool wide) { return cut_entries(wide) * cut_entry_words(wide); }  // what launch_tile_cuts writes per tile
