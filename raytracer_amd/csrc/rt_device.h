@@ -745,7 +745,9 @@ __device__ __forceinline__ WideData wide_fetch(const Trav& tr, const TreeView& t
     const uint32_t at = node * 128u;
     // The loads are written out so that the compiler does not know them for loads: both branches write the same
     // registers, in different lanes, and the compiler would have the LDS reads of the other lanes wait until these loads
-    // have landed.  wide_landed() waits for them.
+    // have landed.  The wait below is for them.  (This relies on the compiler giving the two branches' results the
+    // same registers, with no copy between a load and the wait -- it does, see the assembly; every render of a scene
+    // beyond LDS in the tests would show stale node data at once.)
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(w.NX) : "v"(at + tr.offx), "s"(base) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(w.FX) : "v"(at + (tr.offx ^ 16u)), "s"(base) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=&v"(w.NY) : "v"(at + tr.offy), "s"(base) : "memory");
