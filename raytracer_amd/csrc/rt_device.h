@@ -942,17 +942,35 @@ struct Hit {
 };
 // HitRecord::new (src/hit.rs:18-27) for the sphere in `slot` at distance t.
 // h.material carries the material index (low 30 bits) and type (top 2 bits).
+// What make_hit reads of the sphere in `slot`: asked for first, so that work that does not need it can go on meanwhile.
+// (Centre x, y | centre z | 1/radius, material and index: the radius itself is not read.)
+struct HitData {
+  f64x2 s0;
+  double cz;
+  f64x2 ax;
+};
 template <bool kAllLds>
-__device__ __forceinline__ Hit make_hit(const TreeView& tv, int slot, D3 o, D3 d, double t) {
-  f64x2 s0, s1, ax;
-  fetch_sphere<kAllLds>(tv, (uint32_t)slot, s0, s1);
+__device__ __forceinline__ HitData fetch_hit_data(const TreeView& tv, int slot) {
+  HitData hd;
+  if (kAllLds || (uint32_t)slot < tv.n_sph_lds) {
+    hd.s0 = tv.lsph[2 * slot];
+    hd.cz = ((const lds_double*)(tv.lsph + 2 * slot + 1))[0];
+  } else {
+    const f64x2* p = reinterpret_cast<const f64x2*>(tv.gsph) + 2 * (size_t)slot;
+    hd.s0 = p[0];
+    hd.cz = reinterpret_cast<const double*>(p + 1)[0];
+  }
   if (kAllLds || (uint32_t)slot < tv.n_aux_lds)
-    ax = tv.laux[slot];
+    hd.ax = tv.laux[slot];
   else
-    ax = reinterpret_cast<const f64x2*>(tv.gaux)[slot];
+    hd.ax = reinterpret_cast<const f64x2*>(tv.gaux)[slot];
+  return hd;
+}
+__device__ __forceinline__ Hit make_hit_from(const HitData& hd, D3 o, D3 d, double t) {
+  const f64x2 s0 = hd.s0, ax = hd.ax;
   Hit h;
   h.p = d3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
-  D3 n = ax.x * d3(h.p.x - s0.x, h.p.y - s0.y, h.p.z - s1.x);
+  D3 n = ax.x * d3(h.p.x - s0.x, h.p.y - s0.y, h.p.z - hd.cz);
   h.front = dot(d, n) < 0.0;
   const uint32_t flip = h.front ? 0u : 0x80000000u;  // the normal against the ray: one select and three sign flips
   h.normal = d3(flip_sign(n.x, flip), flip_sign(n.y, flip), flip_sign(n.z, flip));
@@ -960,6 +978,10 @@ __device__ __forceinline__ Hit make_hit(const TreeView& tv, int slot, D3 o, D3 d
   h.material = (uint32_t)bits;
   h.prim = (uint32_t)(bits >> 32);
   return h;
+}
+template <bool kAllLds>
+__device__ __forceinline__ Hit make_hit(const TreeView& tv, int slot, D3 o, D3 d, double t) {
+  return make_hit_from(fetch_hit_data<kAllLds>(tv, slot), o, d, t);
 }
 
 // Material::scatter (src/material.rs:21-65).  `d` is the unit direction of the

@@ -255,9 +255,10 @@ __global__ __launch_bounds__(kWorkgroup) void render_kernel(RenderParams P) {  /
         if (tr.cur == kRefDone && tr.best >= 0) {  // a ray that missed everything is finished by the camera block
           RTA_PROF(BLK_SHADE)
           ++n_rays;
-          const Hit h = make_hit<kAllLds>(tv, tr.best, tr.o, tr.d, tr.t_best);
+          const HitData hd = fetch_hit_data<kAllLds>(tv, tr.best);  // (asked for before the random numbers are worked out, used after)
           double u0, u1;
           philox_pair(P.seed_lo, P.seed_hi, RTA_J * P.cam.width + RTA_I, s, P.cam.max_depth - depth_left, DOM_SCATTER, u0, u1);
+          const Hit h = make_hit_from(hd, tr.o, tr.d, tr.t_best);
           D3 att, nd;
           // None = absorbed (src/camera.rs:108-110); depth exhausted: the path contributes nothing (src/camera.rs:99-101).
           // Everything below is written whether the path goes on or not (what a finished path leaves behind is
